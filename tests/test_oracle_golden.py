@@ -1,0 +1,137 @@
+"""Pins the CPU oracle (oracle/unet_oracle.c and oracle/torch_ref.py) against golden
+vectors produced by the imported reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_c, prng, torch_ref
+
+
+def nerr(a, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(np.asarray(a, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def _checks(grads, g, tag, tol):
+    names = [str(n) for n in g["names"]]
+    sums = g["grad_sums_" + tag]; samp = g["grad_samp_" + tag]; idx = g["grad_samp_idx"]
+    worst = 0.0
+    for i, k in enumerate(names):
+        a = np.asarray(grads[k], dtype=np.float64).ravel()
+        l2 = np.sqrt((a * a).sum())
+        amax = sums[i, 2]
+        assert abs(l2 - sums[i, 1]) <= tol * max(sums[i, 1], 1e-30), (k, l2, sums[i, 1])
+        e = np.abs(a[idx[i]] - samp[i]).max() / max(amax, 1e-30)
+        worst = max(worst, e)
+        assert e <= tol, (k, e)
+    return worst
+
+
+@pytest.mark.parametrize("S", [188, 220])
+def test_c_oracle_f64_matches_reference(golden_dir, S):
+    g = np.load(os.path.join(golden_dir, "unet_S%d.npz" % S))
+    B, So = 2, S - 184
+    p32 = prng.make_params(0)                         # float32 values, widened
+    params = {k: p32[k].astype(np.float64) for k in p32}
+    x = prng.make_input(1, B, S).astype(np.float64)
+    dl = prng.make_cotangent(2, (B, 2, So, So)).astype(np.float64)
+    logits, grads = oracle_c.unet_fwd_bwd(params, x, dlogits=dl)
+    assert nerr(logits, g["logits_f64"]) < 1e-12
+    _checks(grads, g, "f64", 1e-10)
+    for k in ("conv11c.weight", "conv11c.bias", "finalconv.weight", "finalconv.bias", "conv52c.bias", "upconv4.bias"):
+        assert nerr(grads[k], g["grad_full_%s_f64" % k]) < 1e-10, k
+
+
+def test_c_oracle_f32_within_fp32_noise(golden_dir):
+    S = 188
+    g = np.load(os.path.join(golden_dir, "unet_S%d.npz" % S))
+    B, So = 2, S - 184
+    params = prng.make_params(0)
+    x = prng.make_input(1, B, S)
+    dl = prng.make_cotangent(2, (B, 2, So, So))
+    logits, grads = oracle_c.unet_fwd_bwd(params, x, dlogits=dl)
+    # judged against the f64 truth, normalised by tensor scale
+    assert nerr(logits, g["logits_f64"]) < 2e-5
+    _checks(grads, g, "f64", 5e-3)
+
+
+def test_reference_f32_vs_f64_noise_floor(golden_dir):
+    """Records the reference's own fp32-vs-fp64 distance: the bar the HIP path is held to."""
+    for S in (188, 220):
+        g = np.load(os.path.join(golden_dir, "unet_S%d.npz" % S))
+        assert nerr(g["logits_f32"], g["logits_f64"]) < 1e-5
+        rel = np.abs(g["grad_samp_f32"] - g["grad_samp_f64"]).max(axis=1) / g["grad_sums_f64"][:, 2]
+        assert rel.max() < 5e-3
+
+
+def test_torch_ref_matches_reference(golden_dir):
+    S = 220
+    g = np.load(os.path.join(golden_dir, "unet_S%d.npz" % S))
+    p = torch_ref.params_to_torch(prng.make_params(0), torch.float64, requires_grad=True)
+    x = torch.from_numpy(prng.make_input(1, 2, S)).double()
+    y = torch_ref.unet_forward(p, x)
+    assert nerr(y.detach().numpy(), g["logits_f64"]) < 1e-12
+    y.backward(torch.from_numpy(prng.make_cotangent(2, (2, 2, 36, 36))).double())
+    grads = {k: v.grad.numpy() for k, v in p.items()}
+    _checks(grads, g, "f64", 1e-10)
+
+
+def test_c_oracle_S572_forward_and_argmax(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_S572_fwd.npz"))
+    params = prng.make_params(0)
+    x = prng.make_input(1, 1, 572)
+    logits, _ = oracle_c.unet_fwd_bwd(params, x)
+    assert nerr(logits[:, :, ::6, ::6], g["logits_sample_f64"]) < 1e-5
+    am = oracle_c.argmax2(logits).ravel()
+    ref = np.unpackbits(g["argmax_packed"])[: am.size]
+    safe = np.ones(am.size, bool); safe[g["low_margin_idx"]] = False
+    assert (am[safe] == ref[safe]).all()          # bit-exact where the margin allows
+    assert (am != ref).sum() <= g["low_margin_idx"].size
+
+
+def test_known_answers(golden_dir):
+    ka = np.load(os.path.join(golden_dir, "known_answers.npz"))
+    for orig in (196, 388, 512, 1024, 100, 20):
+        assert tuple(ka["isc_%d" % orig]) == oracle_c.input_size_compute(orig)
+    # crop_and_concat: zero-pad (Q2), crop, odd difference raises (Q7)
+    A = np.arange(2 * 3 * 4 * 4, dtype=np.float32).reshape(2, 3, 4, 4)
+    Bt = np.arange(2 * 2 * 8 * 8, dtype=np.float32).reshape(2, 2, 8, 8)
+    assert np.array_equal(oracle_c.crop_and_concat(A, Bt), ka["cac_pad"])
+    assert np.array_equal(oracle_c.crop_and_concat(Bt, A), ka["cac_crop"])
+    assert bool(ka["cac_odd_raises"])
+    with pytest.raises(RuntimeError):
+        oracle_c.crop_and_concat(A, np.zeros((2, 2, 7, 7), np.float32))
+    # L1 / L2
+    g = np.load(os.path.join(golden_dir, "unet_S220.npz"))
+    lg = g["logits_f64"]
+    labels = prng.make_labels(3, 2, 36)
+    ll = np.empty_like(lg); ll[:, 0] = 1 - labels[:, 0]; ll[:, 1] = labels[:, 0]
+    loss, dx = oracle_c.bce_logits(lg, ll)
+    assert abs(loss - ka["bce_plain_loss"]) < 1e-12 * abs(ka["bce_plain_loss"])
+    assert nerr(dx, ka["bce_plain_grad"]) < 1e-12
+    w = ka["class_balance_rand"].astype(np.float64)          # [B,H,W] broadcast against [B,2,H,W] (Q4)
+    loss, dx = oracle_c.bce_logits(lg, ll, w)
+    assert abs(loss - ka["bce_weighted_loss"]) < 1e-12 * abs(ka["bce_weighted_loss"])
+    assert nerr(dx, ka["bce_weighted_grad"]) < 1e-12
+    assert np.array_equal(oracle_c.argmax2(lg), ka["argmax_S220"])
+    assert bool(ka["bce_B3_raises"]) and bool(ka["bce_B8_raises"])
+    # init std formulas (Q1) against the reference's measured init
+    stds = np.array([t[5] for t in prng.layer_table()])
+    assert np.allclose(stds, ka["init_std"], rtol=0.1)   # sqrt(2/N) would be 41% off
+    assert [str(k) for k in ka["init_keys"]] == list(prng.make_params(0, base=4).keys())
+    assert [str(s) for s in ka["init_shapes"]] == [repr(tuple(v.shape)) for v in prng.make_params(0).values()]
+
+
+def test_sgd_oracle_matches_torch():
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal(1000).astype(np.float32); g1 = rng.standard_normal(1000).astype(np.float32)
+    g2 = rng.standard_normal(1000).astype(np.float32)
+    tp = torch.nn.Parameter(torch.from_numpy(p.copy()))
+    opt = torch.optim.SGD([tp], lr=1e-4, momentum=0.99)
+    buf = np.zeros_like(p); q = p.copy()
+    for i, gg in enumerate((g1, g2)):
+        tp.grad = torch.from_numpy(gg.copy()); opt.step()
+        oracle_c.sgd_momentum(q, gg, buf, 1e-4, 0.99, i == 0)
+    assert np.allclose(q, tp.detach().numpy(), rtol=0, atol=1e-7)
