@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — 572x572 tiles/s of the U-Net fwd+bwd step on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic tiles (BASELINE configs[1]:
+batch 8 per GPU, 572x572x1, fp32, 64-base-channel U-Net):
+    zero_grad -> Unet.forward -> BCE-with-logits (unweighted) -> backward
+    [-> RCCL gradient all-reduce, bucketed per backward stage] -> SGD(momentum) -> argmax
+Inputs are resident in HBM before the timed region.  One process per GPU (torch.distributed.run).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     : dominant kernel = the fp32-MFMA implicit GEMM (igemm_f32_kernel); achieved =
+                 algorithmic FLOPs of its launches / their HIP-event time, measured in the timed region
+  cpu_baseline : the torch restatement of the same step (oracle/torch_ref.py) timed on the host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dl-unet_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
+S = 572
+B_PER_GPU = 8
+
+
+def cpu_baseline(max_seconds=30.0):
+    """The reference's CPU path (torch restatement, validated against the imported reference by
+    tests/test_oracle_golden.py) on a bounded sample: B=1 tiles of 572^2, fwd+bwd+SGD steps."""
+    import numpy as np
+    from oracle import prng, torch_ref
+    cores = torch.get_num_threads()
+    p = torch_ref.params_to_torch(prng.make_params(0), torch.float32, requires_grad=True)
+    mom = {}
+    x = torch.from_numpy(prng.make_input(1, 1, S))
+    lab = prng.make_labels(3, 1, S - 184)
+    tgt = torch.from_numpy(np.concatenate([1 - lab, lab], axis=1).astype(np.float32))
+    torch_ref.train_step(p, mom, x, tgt, first=True)                 # warm-up
+    t0 = time.perf_counter(); n = 0
+    while True:
+        torch_ref.train_step(p, mom, x, tgt)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > max_seconds * 0.6 or n >= 6:
+            break
+    return {"value": n / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": "%d fwd+bwd+SGD steps of B=1 572x572 fp32 (torch CPU restatement, %d threads)" % (n, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="tiles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import _hip
+    import network
+    import optim as hip_optim
+    L = _hip.lib()
+
+    torch.manual_seed(0)                                   # same initial weights on every rank
+    net = network.Unet().to(dev)
+    if world > 1:
+        net.enable_data_parallel()
+    opt = hip_optim.SGD(net.parameters(), lr=1e-4, momentum=0.99)
+
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)          # each rank its own shard of the global batch
+    x = torch.rand(B, 1, S, S, generator=g).to(dev)
+    labels = (torch.rand(B, 1, S - 184, S - 184, generator=g) >= 0.5).long().to(dev)
+    target = hip_optim.onehot2(labels, torch.empty(B, 2, S - 184, S - 184, device=dev))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = net(x)
+        loss = hip_optim.bce_with_logits(logits, target)
+        loss.backward()
+        opt.step()
+        return hip_optim.argmax2(logits.detach()), loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timing = not args.no_kernel_timing
+    if timing:
+        L.unet_profile_reset(); L.unet_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        masks, loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if timing:
+        L.unet_profile_enable(0)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        tiles = B * world * args.steps
+        h = network._handle(local_rank)
+        flops_step = h.flops(B, S, True)
+        out = {
+            "metric": "572x572 tiles/sec fwd+bwd", "value": tiles / dt, "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "batch=%d/GPU 572x572x1 fwd+bwd+SGD fp32, 64-base-ch U-Net (BASELINE configs[1])" % B,
+                       "global_batch": B * world, "tile": S, "parallelism": "dp%d" % world,
+                       "loss": "unweighted BCE-with-logits", "final_loss": float(loss.item())},
+            "step_tflops": flops_step / (dt / args.steps) / 1e12,
+        }
+        if timing:
+            ms = C.c_double(); n = C.c_long(); fl = C.c_double()
+            fam = {}
+            for f, name in ((0, "igemm_f32"), (1, "wgrad_f32"), (2, "wgrad_reduce")):
+                _hip.check(L.unet_profile_read(f, C.byref(ms), C.byref(n), C.byref(fl)))
+                fam[name] = (ms.value, n.value, fl.value)
+            ms0, n0, fl0 = fam["igemm_f32"]
+            ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "igemm_f32_kernel (conv fwd / dgrad / up-conv implicit GEMM)",
+                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
+                               "gflop_per_launch": fl0 / max(n0, 1) / 1e9,
+                               "share_of_step_time": ms0 / (dt * 1e3)}
+            ms1, n1, fl1 = fam["wgrad_f32"]
+            out["kernels"] = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
+                                  "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[2] > 0 else None)}
+                              for k, v in fam.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,98 @@
+// common.hpp — shared host/device declarations for libunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace unet {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void set_error(const char *fmt, ...);
+const float *zero_page();          // 4 KiB of device zeros on the current device (lazy, one-time)
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            unet::set_error("%s failed: %s", #expr, hipGetErrorString(e_));        \
+            return (int)e_;                                                        \
+        }                                                                          \
+    } while (0)
+
+#define ARG_CHECK(cond, ...)                                                       \
+    do {                                                                           \
+        if (!(cond)) { unet::set_error(__VA_ARGS__); return -2; }                  \
+    } while (0)
+
+// per-family event timing (prof.hip); family 0 = igemm, 1 = wgrad, 2 = wgrad reduce
+void prof_begin(int family, double flops, hipStream_t st);
+void prof_end(hipStream_t st);
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM descriptor (igemm.hip):  D[m][n] = epi( sum_{src,tap,c} A[m][src,tap,c] * Wt[n][kd] )
+//   m <-> (img, oy, ox) over the output domain [NB, OH, OW]
+//   A row for (src, tap=(ty,tx)) = src.p[img][(oy+oy0)*stride + ty - pad][(ox+ox0)*stride + tx - pad][c0 .. c0+nch)
+//   (zero outside the tensor: virtual zero padding == the reference's crop_and_concat pad, and the
+//    "full" padding of the dgrad correlation)
+//   kd order: source-major, then tap, then channel — the weight packers produce exactly this.
+// ---------------------------------------------------------------------------------------------
+struct GSrc {
+    const float *p;
+    int H, W, C;      // tensor extent per image and channel pitch
+    int c0, nch;      // channel window contributing to K (nch % 32 == 0)
+    int pad;          // virtual zero padding per side
+};
+
+struct IgemmP {
+    GSrc src[2];
+    int nsrc;
+    const float *wt;  // packed weights [Nn][Kd]
+    int Kd;
+    int T, TX;        // taps, taps per row
+    int stride, oy0, ox0;
+    int NB, OH, OW, M, Nn;
+    float *dst;
+    int DH, DW, DC, dn0;
+    int scatter;      // 0: dst pixel == m (DH==OH, DW==OW); 1: up-conv scatter n -> (a,b,co)
+    int cout;         // scatter: channels per (a,b) group; also bias index = n % cout
+    const float *bias;
+    int relu;
+    const float *mask;   // same geometry as dst: v = mask>0 ? v : 0  (ReLU backward)
+    const float *add;    // same geometry as dst: v += add
+    const float *zeros;
+    int mtiles, ntiles;
+};
+int launch_igemm(IgemmP p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient descriptor (wgrad.hip):  D[t][i][j] = sum_{img,y,x} X[img][(y+oy0)*s+ty-xpad][(x+ox0)*s+tx-xpad][xc0+i]
+//                                                                   * Y[img][y][x][yc0+j]
+// computed as split-K partial slabs + a deterministic reduce into out[base + i*si + j*sj + t*st].
+// ---------------------------------------------------------------------------------------------
+struct WgradP {
+    const float *X; int XH, XW, XC, xc0, xpad;
+    const float *Y; int YH, YW, YC, yc0;
+    int NB, stride, TY, TX, oy0, ox0;
+    int ywin0, ywin1, xwin0, xwin1;    // Y-domain window whose taps can touch X
+    int Ci, Cj;                        // multiples of 64
+    float *out; long si, sj, st;       // final gradient tensor strides (elements)
+    float *slab; size_t slab_bytes;    // scratch for partials
+    const float *zeros;
+};
+size_t wgrad_slab_need(const WgradP &p);   // slab bytes launch_wgrad will use for this descriptor
+int launch_wgrad(WgradP p, hipStream_t st);
+
+// Packers from the reference's parameter layouts into the igemm weight matrices (direct.hip)
+int pack_conv_fwd(const float *w_oihw, float *wt, int K, int C1, int C2, hipStream_t st);   // [K][9*C1 | 9*C2]
+int pack_conv_dgrad(const float *w_oihw, float *wt, int K, int C, hipStream_t st);          // [C][9*K], taps flipped
+int pack_upconv_fwd(const float *w_iohw, float *wt, int Ci, int Co, hipStream_t st);        // [4*Co][Ci]
+int pack_upconv_dgrad(const float *w_iohw, float *wt, int Ci, int Co, hipStream_t st);      // [Ci][4*Co]
+int bias_grad(const float *dz, size_t M, int K, float *db, float *scratch, hipStream_t st); // db[k] = sum_m dz[m][k]
+size_t bias_grad_scratch_bytes(size_t M, int K);
+
+}  // namespace unet

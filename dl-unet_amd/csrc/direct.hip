@@ -1,0 +1,625 @@
+// direct.hip — the HBM-bound kernels of the path (no dense contraction worth a matrix core):
+//   conv11c (1 -> K stencil) fwd / weight-grad, 1x1 head fwd / bwd, 2x2 max-pool fwd / bwd,
+//   weight packers, bias gradients, and the step-side kernels (BCE-with-logits, one-hot,
+//   argmax, SGD-momentum).  All are written for 16 B per lane coalesced NHWC traffic.
+#include "common.hpp"
+#include "../../include/unet_hip.h"
+
+namespace unet {
+
+typedef float float4_ __attribute__((ext_vector_type(4)));
+
+// ============================================================================================
+// conv11c: x [B,S,S] (C=1) -> y [B,S-2,S-2,K] NHWC, + bias + ReLU.        network.py:23,131 (A1)
+// 16 lanes per pixel (float4 of channels each) when K=64: every store instruction writes 4 whole
+// pixels = 1 KiB contiguous.  The 9 taps are re-read from L1; the layer is bound by the output write.
+// ============================================================================================
+template <int K>
+__global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ y,
+                                                          int B, int S)
+{
+    constexpr int CG = K / 4;                 // lanes per pixel
+    constexpr int PPB = 256 / CG;             // pixels per pass per block
+    const int So = S - 2;
+    const size_t npix = (size_t)B * So * So;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    float wr[9][4], bv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bv[c] = bias[cg * 4 + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t][c] = w[(cg * 4 + c) * 9 + t];
+    }
+    for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
+        const int img = (int)(pix / ((size_t)So * So));
+        const int rem = (int)(pix - (size_t)img * So * So);
+        const int oy = rem / So, ox = rem - oy * So;
+        const float *xp = x + ((size_t)img * S + oy) * S + ox;
+        float xv[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xv[r * 3 + s] = xp[r * S + s];
+        float4_ o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = bv[c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(xv[t], wr[t][c], a);
+            o[c] = a > 0.f ? a : 0.f;
+        }
+        *(float4_ *)(y + pix * K + cg * 4) = o;
+    }
+}
+
+// dW[k][t] = sum_p x[p+off_t] * dz[p][k],  db[k] = sum_p dz[p][k].   Partials per block, then reduce.
+template <int K>
+__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                            float *__restrict__ partial, int B, int S)
+{
+    constexpr int CG = K / 4, PPB = 256 / CG;
+    const int So = S - 2;
+    const size_t npix = (size_t)B * So * So;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    float acc[10][4];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+    for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
+        const int img = (int)(pix / ((size_t)So * So));
+        const int rem = (int)(pix - (size_t)img * So * So);
+        const int oy = rem / So, ox = rem - oy * So;
+        const float *xp = x + ((size_t)img * S + oy) * S + ox;
+        const float4_ g = *(const float4_ *)(dz + pix * K + cg * 4);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const float xv = xp[r * S + s];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r * 3 + s][c] = fmaf(xv, g[c], acc[r * 3 + s][c]);
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[9][c] += g[c];
+    }
+    // block reduction over the PPB pixel slots through LDS: red[pl][t][k]
+    __shared__ float red[PPB][10 * K / 4 + 1][4];   // (+1 pad row) indexed [pl][t*CG+cg][c]
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[pl][t * CG + cg][c] = acc[t][c];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 10 * K; e += 256) {
+        const int t = e / K, kk = e - t * K;
+        float s = 0.f;
+        for (int q = 0; q < PPB; ++q) s += red[q][t * CG + kk / 4][kk & 3];
+        partial[(size_t)blockIdx.x * 10 * K + e] = s;
+    }
+}
+
+// out: dw[k][t] (t<9) and db[k] from partial[nb][10][K]
+__global__ void conv1ch_wgrad_reduce_kernel(const float *__restrict__ partial, int nb, int K,
+                                            float *__restrict__ dw, float *__restrict__ db)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 10 * K) return;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 2 <= nb; b += 2) { s0 += partial[(size_t)b * 10 * K + e]; s1 += partial[(size_t)(b + 1) * 10 * K + e]; }
+    if (b < nb) s0 += partial[(size_t)b * 10 * K + e];
+    const int t = e / K, kk = e - t * K;
+    if (t < 9) { if (dw) dw[kk * 9 + t] = s0 + s1; } else if (db) db[kk] = s0 + s1;
+}
+
+// ============================================================================================
+// head: finalconv 1x1, C -> 2, NHWC in, NCHW logits out.                 network.py:58,190 (A22)
+// 16 lanes x float4 cover a pixel's channels (C=64); partial dot products are combined with
+// wave shuffles, results staged in LDS so the two class planes are written coalesced.
+// ============================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ logits,
+                                                          int B, int HW)
+{
+    constexpr int CG = C / 4, PPP = 256 / CG;       // pixels per pass
+    constexpr int PASSES = 16;
+    constexpr int PPB = PPP * PASSES;               // pixels per block
+    __shared__ float outs[2][PPB];
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    float4_ w0 = *(const float4_ *)(w + cg * 4), w1 = *(const float4_ *)(w + C + cg * 4);
+    const float b0 = bias[0], b1 = bias[1];
+    const size_t npix = (size_t)B * HW;
+    const size_t base = (size_t)blockIdx.x * PPB;
+#pragma unroll 4
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int lp = ps * PPP + pl;
+        const size_t pix = base + lp;
+        float s0 = 0.f, s1 = 0.f;
+        if (pix < npix) {
+            const float4_ v = *(const float4_ *)(x + pix * C + cg * 4);
+            s0 = v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+            s1 = v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
+        }
+#pragma unroll
+        for (int d = CG / 2; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); }
+        if (cg == 0) { outs[0][lp] = s0 + b0; outs[1][lp] = s1 + b1; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * PPB; e += 256) {
+        const int k = e / PPB, lp = e - k * PPB;
+        const size_t pix = base + lp;
+        if (pix < npix) {
+            const size_t img = pix / HW, rem = pix - img * HW;
+            logits[(img * 2 + k) * HW + rem] = outs[k][lp];
+        }
+    }
+}
+
+// backward: dz[m][c] = (dl0[m]*w[0][c] + dl1[m]*w[1][c]) * (x[m][c] > 0);
+//           dw[k][c] = sum_m dl_k[m]*x[m][c];  db[k] = sum_m dl_k[m]   (partials per block)
+template <int C>
+__global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ dlogits, float *__restrict__ dz,
+                                                          float *__restrict__ partial, int B, int HW)
+{
+    constexpr int CG = C / 4, PPP = 256 / CG;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    const float4_ w0 = *(const float4_ *)(w + cg * 4), w1 = *(const float4_ *)(w + C + cg * 4);
+    const size_t npix = (size_t)B * HW;
+    float4_ a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    float sb0 = 0.f, sb1 = 0.f;
+    for (size_t pix = (size_t)blockIdx.x * PPP + pl; pix < npix; pix += (size_t)gridDim.x * PPP) {
+        const size_t img = pix / HW, rem = pix - img * HW;
+        const float d0 = dlogits[(img * 2) * HW + rem], d1 = dlogits[(img * 2 + 1) * HW + rem];
+        const float4_ v = *(const float4_ *)(x + pix * C + cg * 4);
+        float4_ g;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            g[c] = v[c] > 0.f ? d0 * w0[c] + d1 * w1[c] : 0.f;
+            a0[c] = fmaf(d0, v[c], a0[c]);
+            a1[c] = fmaf(d1, v[c], a1[c]);
+        }
+        *(float4_ *)(dz + pix * C + cg * 4) = g;
+        sb0 += d0; sb1 += d1;
+    }
+    __shared__ float red[PPP][2 * C + 2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[pl][cg * 4 + c] = a0[c]; red[pl][C + cg * 4 + c] = a1[c]; }
+    if (cg == 0) { red[pl][2 * C] = sb0; red[pl][2 * C + 1] = sb1; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C + 2; e += 256) {
+        float s = 0.f;
+        for (int q = 0; q < PPP; ++q) s += red[q][e];
+        partial[(size_t)blockIdx.x * (2 * C + 2) + e] = s;
+    }
+}
+
+__global__ void head1x1_bwd_reduce_kernel(const float *__restrict__ partial, int nb, int C,
+                                          float *__restrict__ dw, float *__restrict__ db)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * C + 2) return;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 2 <= nb; b += 2) { s0 += partial[(size_t)b * (2 * C + 2) + e]; s1 += partial[(size_t)(b + 1) * (2 * C + 2) + e]; }
+    if (b < nb) s0 += partial[(size_t)b * (2 * C + 2) + e];
+    if (e < 2 * C) { if (dw) dw[e] = s0 + s1; } else if (db) db[e - 2 * C] = s0 + s1;
+}
+
+// ============================================================================================
+// 2x2 max-pool, NHWC.                                                  network.py:133-151 (A3)
+// ============================================================================================
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           int B, int H, int W, int C4)
+{
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t pp = e / C4;
+        const int ox = (int)(pp % Wo); pp /= Wo;
+        const int oy = (int)(pp % Ho);
+        const int img = (int)(pp / Ho);
+        const float4_ *src = (const float4_ *)x + (((size_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const float4_ v00 = src[0], v01 = src[C4], v10 = src[(size_t)W * C4], v11 = src[(size_t)W * C4 + C4];
+        float4_ m;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaxf(v00[c], v01[c]), fmaxf(v10[c], v11[c]));
+        ((float4_ *)y)[e] = m;
+    }
+}
+
+// dpre = route(dy to the first maximum in row-major window order) * (pre > 0)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restrict__ pre, const float *__restrict__ dy,
+                                                           float *__restrict__ dpre, int B, int H, int W, int C4)
+{
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t pp = e / C4;
+        const int ox = (int)(pp % Wo); pp /= Wo;
+        const int oy = (int)(pp % Ho);
+        const int img = (int)(pp / Ho);
+        const size_t o00 = (((size_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const size_t o01 = o00 + C4, o10 = o00 + (size_t)W * C4, o11 = o10 + C4;
+        const float4_ v00 = ((const float4_ *)pre)[o00], v01 = ((const float4_ *)pre)[o01];
+        const float4_ v10 = ((const float4_ *)pre)[o10], v11 = ((const float4_ *)pre)[o11];
+        const float4_ g = ((const float4_ *)dy)[e];
+        float4_ g00, g01, g10, g11;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float m = v00[c]; int mi = 0;
+            if (v01[c] > m) { m = v01[c]; mi = 1; }
+            if (v10[c] > m) { m = v10[c]; mi = 2; }
+            if (v11[c] > m) { m = v11[c]; mi = 3; }
+            const float gv = m > 0.f ? g[c] : 0.f;
+            g00[c] = mi == 0 ? gv : 0.f; g01[c] = mi == 1 ? gv : 0.f;
+            g10[c] = mi == 2 ? gv : 0.f; g11[c] = mi == 3 ? gv : 0.f;
+        }
+        ((float4_ *)dpre)[o00] = g00; ((float4_ *)dpre)[o01] = g01;
+        ((float4_ *)dpre)[o10] = g10; ((float4_ *)dpre)[o11] = g11;
+    }
+}
+
+// ============================================================================================
+// Weight packers: reference layouts (OIHW / IOHW) -> igemm weight matrices [N][Kd].
+// ============================================================================================
+// conv fwd: wt[k][kd], kd = (c<C1 ? t*C1 + c : 9*C1 + t*C2 + (c-C1));  w[k][c][t]
+__global__ void pack_conv_fwd_kernel(const float *__restrict__ w, float *__restrict__ wt, int K, int C1, int C2)
+{
+    const int C = C1 + C2;
+    const size_t total = (size_t)K * C * 9;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int kd = (int)(e % (9 * C));
+        const int k = (int)(e / (9 * C));
+        int c, t;
+        if (kd < 9 * C1) { t = kd / C1; c = kd - t * C1; }
+        else { const int r = kd - 9 * C1; t = r / C2; c = C1 + r - t * C2; }
+        wt[e] = w[((size_t)k * C + c) * 9 + t];
+    }
+}
+// conv dgrad: wt[c][t'*K + k] = w[k][c][8 - t']
+__global__ void pack_conv_dgrad_kernel(const float *__restrict__ w, float *__restrict__ wt, int K, int C)
+{
+    const size_t total = (size_t)K * C * 9;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int kd = (int)(e % (9 * K));
+        const int c = (int)(e / (9 * K));
+        const int t = kd / K, k = kd - t * K;
+        wt[e] = w[((size_t)k * C + c) * 9 + (8 - t)];
+    }
+}
+// up-conv fwd: wt[(ab)*Co + co][ci] = w[ci][co][ab]
+__global__ void pack_upconv_fwd_kernel(const float *__restrict__ w, float *__restrict__ wt, int Ci, int Co)
+{
+    const size_t total = (size_t)Ci * Co * 4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(e % Ci);
+        const int n = (int)(e / Ci);
+        const int ab = n / Co, co = n - ab * Co;
+        wt[e] = w[((size_t)ci * Co + co) * 4 + ab];
+    }
+}
+// up-conv dgrad: wt[ci][(ab)*Co + co] = w[ci][co][ab]
+__global__ void pack_upconv_dgrad_kernel(const float *__restrict__ w, float *__restrict__ wt, int Ci, int Co)
+{
+    const size_t total = (size_t)Ci * Co * 4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int kd = (int)(e % (4 * Co));
+        const int ci = (int)(e / (4 * Co));
+        const int ab = kd / Co, co = kd - ab * Co;
+        wt[e] = w[((size_t)ci * Co + co) * 4 + ab];
+    }
+}
+
+static inline int grid_for(size_t total, int per_block = 256, int cap = 8192)
+{
+    size_t g = (total + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+int pack_conv_fwd(const float *w, float *wt, int K, int C1, int C2, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_conv_fwd_kernel, dim3(grid_for((size_t)K * (C1 + C2) * 9)), dim3(256), 0, st, w, wt, K, C1, C2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pack_conv_dgrad(const float *w, float *wt, int K, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3(grid_for((size_t)K * C * 9)), dim3(256), 0, st, w, wt, K, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pack_upconv_fwd(const float *w, float *wt, int Ci, int Co, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_upconv_fwd_kernel, dim3(grid_for((size_t)Ci * Co * 4)), dim3(256), 0, st, w, wt, Ci, Co);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pack_upconv_dgrad(const float *w, float *wt, int Ci, int Co, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_upconv_dgrad_kernel, dim3(grid_for((size_t)Ci * Co * 4)), dim3(256), 0, st, w, wt, Ci, Co);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ============================================================================================
+// bias gradient: db[k] = sum_m dz[m][k]  (column sums of an [M][K] matrix), two deterministic passes
+// (for the up-conv bias the caller passes M*4 rows of Cout).
+// ============================================================================================
+constexpr int BG_ROWS = 2048;     // rows per block in pass 1
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dz, size_t M, int K,
+                                                        float *__restrict__ partial)
+{
+    // thread -> (channel group of 4, row slot); K/4 groups, 256/(K/4) row slots (K/4 <= 256)
+    const int CG = K >> 2;
+    const int slots = 256 / CG;
+    const int cg = threadIdx.x % CG, sl = threadIdx.x / CG;
+    const size_t r0 = (size_t)blockIdx.x * BG_ROWS;
+    size_t r1 = r0 + BG_ROWS; r1 = r1 < M ? r1 : M;
+    float4_ a = {0, 0, 0, 0};
+    if (sl < slots)
+        for (size_t r = r0 + sl; r < r1; r += slots) {
+            const float4_ v = *(const float4_ *)(dz + r * K + cg * 4);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+    __shared__ float4_ red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < CG) {
+        float4_ s = {0, 0, 0, 0};
+        for (int q = 0; q < slots; ++q) { const float4_ v = red[q * CG + threadIdx.x]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+        *(float4_ *)(partial + (size_t)blockIdx.x * K + threadIdx.x * 4) = s;
+    }
+}
+__global__ void bias_grad_reduce_kernel(const float *__restrict__ partial, int nb, int K, float *__restrict__ db)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nb; b += 4) {
+        s0 += partial[(size_t)b * K + k]; s1 += partial[(size_t)(b + 1) * K + k];
+        s2 += partial[(size_t)(b + 2) * K + k]; s3 += partial[(size_t)(b + 3) * K + k];
+    }
+    for (; b < nb; ++b) s0 += partial[(size_t)b * K + k];
+    db[k] = (s0 + s1) + (s2 + s3);
+}
+size_t bias_grad_scratch_bytes(size_t M, int K) { return ((M + BG_ROWS - 1) / BG_ROWS) * K * sizeof(float); }
+int bias_grad(const float *dz, size_t M, int K, float *db, float *scratch, hipStream_t st)
+{
+    ARG_CHECK(K % 4 == 0 && K / 4 <= 256, "bias_grad: K=%d unsupported", K);
+    const int nb = (int)((M + BG_ROWS - 1) / BG_ROWS);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(256), 0, st, dz, M, K, scratch);
+    hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, scratch, nb, K, db);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ============================================================================================
+// Step-side kernels (L1-L3)
+// ============================================================================================
+constexpr int BCE_PER_BLOCK = 4096;
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float *__restrict__ x, const float *__restrict__ z,
+                                                         const float *__restrict__ w, long wsB, long wsC, long wsH, long wsW,
+                                                         int H, int W, size_t n, float *__restrict__ dx, float gscale,
+                                                         double *__restrict__ partial)
+{
+    const size_t b0 = (size_t)blockIdx.x * BCE_PER_BLOCK;
+    double acc = 0.0;
+    const float inv_n = (float)(1.0 / (double)n);
+    for (int i = threadIdx.x; i < BCE_PER_BLOCK; i += 256) {
+        const size_t e = b0 + i;
+        if (e >= n) break;
+        const float xv = x[e], zv = z[e];
+        float wv = 1.f;
+        if (w) {
+            size_t r = e;
+            const int xx = (int)(r % W); r /= W;
+            const int yy = (int)(r % H); r /= H;
+            const int cc = (int)(r % 2);
+            const long bb = (long)(r / 2);
+            wv = w[bb * wsB + cc * wsC + yy * wsH + xx * wsW];
+        }
+        const float ax = fabsf(xv);
+        const float l = fmaxf(xv, 0.f) - xv * zv + log1pf(expf(-ax));
+        acc += (double)(wv * l);
+        if (dx) {
+            const float ex = expf(-ax);
+            const float sg = xv >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
+            dx[e] = wv * (sg - zv) * inv_n * gscale;
+        }
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void bce_final_kernel(const double *__restrict__ partial, int nb, size_t n, float *loss)
+{
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] / (double)n);
+}
+
+__global__ void onehot2_kernel(const long long *__restrict__ labels, float *__restrict__ t, int B, size_t HW)
+{
+    const size_t total = (size_t)B * HW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = e / HW, rem = e - img * HW;
+        const float y = (float)labels[e];
+        t[(img * 2) * HW + rem] = 1.f - y;
+        t[(img * 2 + 1) * HW + rem] = y;
+    }
+}
+
+__global__ void argmax2_kernel(const float *__restrict__ x, long bs, long ps, long rs, long long *__restrict__ out,
+                               int B, int H, int W)
+{
+    const size_t total = (size_t)B * H * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t r = e;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const long b = (long)(r / H);
+        const float *p = x + b * bs + yy * rs + xx;
+        out[e] = p[ps] > p[0] ? 1 : 0;            // first maximum wins on ties -> class 0
+    }
+}
+
+struct SgdTable { float *p[UNET_N_PARAMS]; const float *g[UNET_N_PARAMS]; float *b[UNET_N_PARAMS];
+                  unsigned long long start[UNET_N_PARAMS + 1]; int n; };
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(const SgdTable tb, float lr, float mu, int first)
+{
+    // each block handles 4096 consecutive elements of the virtual concatenation of all tensors
+    const unsigned long long total = tb.start[tb.n];
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 4096; base < total; base += (unsigned long long)gridDim.x * 4096) {
+        int t = 0;
+        while (t + 1 < tb.n && tb.start[t + 1] <= base) ++t;
+        for (int i = threadIdx.x; i < 4096; i += 256) {
+            unsigned long long e = base + i;
+            if (e >= total) break;
+            while (tb.start[t + 1] <= e) ++t;
+            const unsigned long long o = e - tb.start[t];
+            const float g = tb.g[t][o];
+            const float b = first ? g : fmaf(mu, tb.b[t][o], g);
+            tb.b[t][o] = b;
+            tb.p[t][o] -= lr * b;
+        }
+    }
+}
+
+}  // namespace unet
+
+using namespace unet;
+
+extern "C" {
+
+int unet_conv1ch_fwd(const void *x, int B, int S, const void *w, const void *bias, int K, void *y, void *stream)
+{
+    ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
+    const size_t npix = (size_t)B * (S - 2) * (S - 2);
+    const int ppb = 256 / (K / 4);
+    const int grid = grid_for(npix, ppb * 8, 16384);
+    if (K == 64) hipLaunchKernelGGL(conv1ch_fwd_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)y, B, S);
+    else hipLaunchKernelGGL(conv1ch_fwd_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)y, B, S);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int conv1ch_bwd_blocks(int B, int S) { const size_t npix = (size_t)B * (S - 2) * (S - 2); return grid_for(npix, 16 * 64, 2048); }
+size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K) { return (size_t)conv1ch_bwd_blocks(B, S) * 10 * K * sizeof(float); }
+int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *dw, void *db, void *scratch, void *stream)
+{
+    ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
+    const int nb = conv1ch_bwd_blocks(B, S);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 64) hipLaunchKernelGGL(conv1ch_wgrad_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)dz, (float *)scratch, B, S);
+    else hipLaunchKernelGGL(conv1ch_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)dz, (float *)scratch, B, S);
+    hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(cdiv(10 * K, 256)), dim3(256), 0, st, (const float *)scratch, nb, K, (float *)dw, (float *)db);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int unet_head1x1_fwd(const void *x, int B, int H, int W, int C, const void *w, const void *bias, void *logits, void *stream)
+{
+    ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
+    const size_t npix = (size_t)B * H * W;
+    const int ppb = (256 / (C / 4)) * 16;
+    const int grid = (int)((npix + ppb - 1) / ppb);
+    if (C == 64) hipLaunchKernelGGL(head1x1_fwd_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
+    else hipLaunchKernelGGL(head1x1_fwd_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 2048); }
+size_t unet_head1x1_bwd_scratch_bytes(int B, int H, int W, int C) { return (size_t)head_bwd_blocks(B, H, W) * (2 * C + 2) * sizeof(float); }
+int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, const void *dlogits, void *dz,
+                     void *dw, void *db, void *scratch, void *stream)
+{
+    ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
+    const int nb = head_bwd_blocks(B, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 64) hipLaunchKernelGGL(head1x1_bwd_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
+    else hipLaunchKernelGGL(head1x1_bwd_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
+    hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 256)), dim3(256), 0, st, (const float *)scratch, nb, C, (float *)dw, (float *)db);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int unet_maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, void *stream)
+{
+    ARG_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: H,W must be even and C a multiple of 4");
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (const float *)x, (float *)y, B, H, W, C / 4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int unet_maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, void *stream)
+{
+    ARG_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: H,W must be even and C a multiple of 4");
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (const float *)pre, (const float *)dy, (float *)dpre, B, H, W, C / 4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t unet_bce_scratch_bytes(size_t numel) { return ((numel + BCE_PER_BLOCK - 1) / BCE_PER_BLOCK) * sizeof(double); }
+int unet_bce_logits(const void *logits, const void *target, const void *weight, long wsB, long wsC, long wsH, long wsW,
+                    int B, int H, int W, void *loss_out, void *dlogits, float grad_scale, void *scratch, void *stream)
+{
+    const size_t n = (size_t)B * 2 * H * W;
+    ARG_CHECK(n > 0 && loss_out && scratch, "bce: bad arguments");
+    const int nb = (int)((n + BCE_PER_BLOCK - 1) / BCE_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(nb), dim3(256), 0, st, (const float *)logits, (const float *)target, (const float *)weight,
+                       wsB, wsC, wsH, wsW, H, W, n, (float *)dlogits, grad_scale, (double *)scratch);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, (const double *)scratch, nb, n, (float *)loss_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int unet_onehot2(const void *labels_i64, void *target, int B, int H, int W, void *stream)
+{
+    hipLaunchKernelGGL(onehot2_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, (const long long *)labels_i64, (float *)target, B, (size_t)H * W);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int unet_argmax2(const void *logits, long batch_stride, long plane_stride, long row_stride, void *out_i64, int B, int H, int W, void *stream)
+{
+    hipLaunchKernelGGL(argmax2_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, (const float *)logits, batch_stride, plane_stride, row_stride, (long long *)out_i64, B, H, W);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int unet_sgd_momentum(void *const *params, const void *const *grads, void *const *bufs, const size_t *numel, int n,
+                      float lr, float mu, int first_step, void *stream)
+{
+    ARG_CHECK(n > 0 && n <= UNET_N_PARAMS, "sgd: n=%d out of range (1..%d)", n, UNET_N_PARAMS);
+    SgdTable tb;
+    tb.n = n;
+    unsigned long long off = 0;
+    for (int i = 0; i < n; ++i) {
+        tb.p[i] = (float *)params[i]; tb.g[i] = (const float *)grads[i]; tb.b[i] = (float *)bufs[i];
+        tb.start[i] = off; off += numel[i];
+    }
+    tb.start[n] = off;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(off, 4096, 8192)), dim3(256), 0, (hipStream_t)stream, tb, lr, mu, first_step);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

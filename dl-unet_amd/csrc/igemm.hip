@@ -1,0 +1,303 @@
+// igemm.hip — fp32 implicit-GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family serves every dense contraction on the path:
+//   conv3x3 fwd (+bias+ReLU, virtual zero-pad-concat of two sources)   network.py:131-188
+//   conv3x3 dgrad (full correlation with the flipped filter, + ReLU' mask / + skip gradient)
+//   up-conv 2x2 s2 fwd (GEMM + scatter store) and dgrad (4 taps, stride 2)   network.py:159-183
+//
+// Why MFMA for all of them: in fp32 every 3x3 layer with Cin >= 64 has 143-730 FLOP/B of
+// algorithmic intensity against a ridge of ~20 FLOP/B, i.e. they are bound by the fp32 FMA rate;
+// the f32 MFMA has the VALU's peak rate (64 FLOP/clk/SIMD) with exact fmaf-chain numerics, needs
+// one VGPR per operand and leaves the VALU free for addressing.
+//
+// Tile: BM x BN outputs per 256-thread workgroup (4 waves, each a 64x64 tile = 2x2 MFMA tiles of
+// 32x32), K step 32.  Operands are staged global -> LDS with global_load_lds_dwordx4 (no VGPR
+// round trip), double buffered, one barrier per K step.  LDS rows are 128 B (32 floats of K); the
+// 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE address and on the fragment
+// read, which makes the ds_read_b128 fragment reads bank-conflict free.
+#include "common.hpp"
+
+namespace unet {
+
+#define GLDS16(gptr, lptr)                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int BM, int BN, bool PAD>
+__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
+{
+    constexpr int WN = BN / 64;                 // waves along N
+    constexpr int WM = 4 / WN;                  // waves along M
+    static_assert(WM * 64 == BM, "4 waves of 64x64");
+    constexpr int RA = BM / 32, RB = BN / 32;   // staging rows per thread
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give every XCD a
+    // contiguous run of logical tiles; N-tiles of one M-tile are neighbours and reuse the A rows.
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int mt = logical / p.ntiles, nt = logical - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- staging geometry: thread -> (row within a 32-row pass, 16-B chunk position)
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);   // swizzled SOURCE chunk for this LDS slot
+    const int coff = schunk * 4;
+
+    int a_off[RA], a_iy[RA], a_ix[RA];
+    int b_off[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        int n = n0 + srow + 32 * j;
+        n = n < p.Nn ? n : p.Nn - 1;
+        b_off[j] = n * p.Kd + coff;
+    }
+
+    int s = 0, ty = 0, tx = 0, kc = 0, kglob = 0;
+    const float *sp = nullptr;
+    int sH = 0, sW = 0, sC = 0, snch = 0, toff = 0;
+
+    auto setup_source = [&](int si) {
+        const GSrc &g = p.src[si];
+        sp = g.p; sH = g.H; sW = g.W; sC = g.C; snch = g.nch;
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int m = m0 + srow + 32 * i;
+            m = m < p.M ? m : p.M - 1;
+            const int img = m / ohw;
+            const int rem = m - img * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            const int iy = (oy + p.oy0) * p.stride - g.pad;
+            const int ix = (ox + p.ox0) * p.stride - g.pad;
+            a_iy[i] = iy; a_ix[i] = ix;
+            a_off[i] = ((img * g.H + iy) * g.W + ix) * g.C + g.c0 + coff;
+        }
+        toff = 0;
+    };
+
+    auto stage = [&](int buf) {
+        unsigned char *abase = smem + buf * STAGE + wave * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const float *g = sp + (a_off[i] + toff + kc);
+            if (PAD) {
+                const bool inb = (unsigned)(a_iy[i] + ty) < (unsigned)sH &&
+                                 (unsigned)(a_ix[i] + tx) < (unsigned)sW;
+                g = inb ? g : p.zeros + coff;
+            }
+            GLDS16(g, abase + i * (32 * 128));
+        }
+        unsigned char *bbase = abase + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) GLDS16(p.wt + (b_off[j] + kglob), bbase + j * (32 * 128));
+    };
+
+    auto advance = [&]() {
+        kglob += 32;
+        kc += 32;
+        if (kc == snch) {
+            kc = 0;
+            ++tx;
+            if (tx == p.TX) { tx = 0; ++ty; }
+            if (ty * p.TX + tx == p.T) {
+                ty = 0; tx = 0;
+                ++s;
+                if (s < p.nsrc) setup_source(s);
+            } else {
+                toff = (ty * sW + tx) * sC;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int a_rd = (wm * 64 + l31) * 128;
+    const int b_rd = A_BYTES + (wn * 64 + l31) * 128;
+
+    const int nk = p.Kd >> 5;
+    setup_source(0);
+    stage(0);
+    advance();
+    __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes buffer 0
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) { stage(cur ^ 1); advance(); }
+        const unsigned char *sb = smem + cur * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int pos = ((2 * g + lh) ^ swz) * 16;
+            const f32x4 a0 = *(const f32x4 *)(sb + a_rd + pos);
+            const f32x4 a1 = *(const f32x4 *)(sb + a_rd + 32 * 128 + pos);
+            const f32x4 b0 = *(const f32x4 *)(sb + b_rd + pos);
+            const f32x4 b1 = *(const f32x4 *)(sb + b_rd + 32 * 128 + pos);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
+    }
+
+    // ---- epilogue: per-row destination offsets through LDS, then bias / add / ReLU / mask / store.
+    // Rows past M get row M-1's (valid) offset so every mask/add load can be issued unconditionally
+    // and back to back; only the store is predicated.
+    unsigned *rowoff = (unsigned *)smem;
+    if (tid < BM) {
+        int m = m0 + tid;
+        m = m < p.M ? m : p.M - 1;
+        unsigned off;
+        if (!p.scatter) {
+            off = (unsigned)m * (unsigned)p.DC;
+        } else {
+            const int ohw = p.OH * p.OW;
+            const int img = m / ohw;
+            const int rem = m - img * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int n_raw = n0 + wn * 64 + tn * 32 + l31;
+        const bool n_ok = n_raw < p.Nn;
+        const int n = n_ok ? n_raw : p.Nn - 1;
+        int coloff, bidx;
+        if (!p.scatter) {
+            coloff = p.dn0 + n;
+            bidx = p.cout ? n % p.cout : n;
+        } else {
+            const int ab = n / p.cout;
+            bidx = n - ab * p.cout;
+            coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + bidx;
+        }
+        const float bv = p.bias ? p.bias[bidx] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            size_t o[16];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                o[r] = (size_t)rowoff[row] + (size_t)coloff;
+                v[r] = acc[tm][tn][r] + bv;
+            }
+            if (p.add) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = p.add[o[r]];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += t[r];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            if (p.mask) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = p.mask[o[r]];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m0 + row < p.M) p.dst[o[r]] = v[r];
+            }
+        }
+    }
+}
+
+// Algorithmic FLOPs of one launch: 2 * (in-bounds (pixel, tap) pairs) * channels * N.  Taps that fall
+// into the virtual zero padding are not counted (they are work the tiling does, not work the op needs).
+static double igemm_alg_flops(const IgemmP &p)
+{
+    double total = 0.0;
+    const int TYn = p.T / p.TX;
+    for (int s = 0; s < p.nsrc; ++s) {
+        long cy = 0, cx = 0;
+        for (int o = 0; o < p.OH; ++o)
+            for (int t = 0; t < TYn; ++t) { const int i = (o + p.oy0) * p.stride - p.src[s].pad + t; cy += (i >= 0 && i < p.src[s].H); }
+        for (int o = 0; o < p.OW; ++o)
+            for (int t = 0; t < p.TX; ++t) { const int i = (o + p.ox0) * p.stride - p.src[s].pad + t; cx += (i >= 0 && i < p.src[s].W); }
+        total += 2.0 * p.NB * (double)cy * (double)cx * p.src[s].nch * p.Nn;
+    }
+    return total;
+}
+
+template <int BM, int BN, bool PAD>
+static int launch_cfg(const IgemmP &p, hipStream_t st)
+{
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    auto kern = igemm_f32_kernel<BM, BN, PAD>;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    IgemmP q = p;
+    q.mtiles = cdiv(p.M, BM);
+    q.ntiles = cdiv(p.Nn, BN);
+    prof_begin(0, igemm_alg_flops(p), st);
+    hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_igemm(IgemmP p, hipStream_t st)
+{
+    ARG_CHECK(p.nsrc == 1 || p.nsrc == 2, "igemm: nsrc must be 1 or 2");
+    int kd = 0;
+    bool pad = false;
+    for (int i = 0; i < p.nsrc; ++i) {
+        ARG_CHECK(p.src[i].nch > 0 && p.src[i].nch % 32 == 0, "igemm: channel count %d is not a multiple of 32", p.src[i].nch);
+        ARG_CHECK(p.src[i].C % 4 == 0 && p.src[i].c0 % 4 == 0, "igemm: channel pitch/offset must be multiples of 4");
+        kd += p.src[i].nch * p.T;
+        // a source is "padded" if any tap can fall outside it
+        const int lo = p.oy0 * p.stride - p.src[i].pad;
+        const int hi_y = (p.OH - 1 + p.oy0) * p.stride - p.src[i].pad + (p.T / p.TX - 1);
+        const int hi_x = (p.OW - 1 + p.ox0) * p.stride - p.src[i].pad + (p.TX - 1);
+        const int lo_x = p.ox0 * p.stride - p.src[i].pad;
+        if (lo < 0 || lo_x < 0 || hi_y >= p.src[i].H || hi_x >= p.src[i].W) pad = true;
+    }
+    ARG_CHECK(kd == p.Kd, "igemm: Kd %d does not match sources (%d)", p.Kd, kd);
+    ARG_CHECK(p.M == p.NB * p.OH * p.OW && p.M > 0 && p.Nn > 0, "igemm: bad M/N");
+    if (!p.scatter) ARG_CHECK(p.DH == p.OH && p.DW == p.OW, "igemm: linear store needs dst extent == output domain");
+    ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0xFFFFFFFFull, "igemm: destination exceeds 32-bit element offsets");
+    for (int i = 0; i < p.nsrc; ++i)
+        ARG_CHECK((size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C < 0x7FFFFFFFull, "igemm: source exceeds 31-bit element offsets");
+    p.zeros = zero_page();
+    if (!p.zeros) return -2;
+    if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true>(p, st) : launch_cfg<128, 128, false>(p, st);
+    return pad ? launch_cfg<256, 64, true>(p, st) : launch_cfg<256, 64, false>(p, st);
+}
+
+}  // namespace unet

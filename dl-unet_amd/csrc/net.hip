@@ -1,0 +1,678 @@
+// net.hip — the C ABI of libunet_hip.so: plan, workspace layout, Unet forward / backward
+// orchestration and the per-op entry points (see include/unet_hip.h for the contract and the
+// reference lines each entry point replaces).
+#include "common.hpp"
+#include "../../include/unet_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace unet {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static float *g_zero[64] = {nullptr};
+static std::mutex g_zero_mu;
+const float *zero_page()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("zero_page: bad device"); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_zero_mu);
+    if (!g_zero[dev]) {
+        float *p = nullptr;
+        if (hipMalloc((void **)&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess) {
+            set_error("zero_page: hipMalloc failed");
+            return nullptr;
+        }
+        g_zero[dev] = p;
+    }
+    return g_zero[dev];
+}
+
+// layer indices in the reference's declaration order (network.py:23-58)
+enum { C11C, C12C, C21C, C22C, C31C, C32C, C41C, C42C, C51C, C52C, UP4, C41E, C42E, UP3, C31E, C32E,
+       UP2, C21E, C22E, UP1, C11E, C12E, FINAL };
+static const int UP_L[4] = {UP1, UP2, UP3, UP4};
+static const int C1E_L[4] = {C11E, C21E, C31E, C41E};
+static const int C2E_L[4] = {C12E, C22E, C32E, C42E};
+
+struct Plan {
+    int B = 0, S = 0, base = 0, So = 0, training = 0;
+    int ch[5];
+    int ein[5], ea1[5], ea2[5], et[4], eu[4], ed1[4], ed2[4], pad[4];
+    size_t a1[5], a2[5], t[4], u[4], d1[4], d2[4];
+    size_t wt_fwd[UNET_N_LAYERS], wt_bwd[UNET_N_LAYERS];
+    size_t g_a1[5], g_a2[5], g_t[4], g_ts[4], g_u[4], g_d1[4], g_d2[4];
+    size_t slab = 0, slab_bytes = 0, small = 0, small_bytes = 0, xin = 0;
+    size_t total = 0;
+};
+
+}  // namespace unet
+
+using namespace unet;
+
+struct unet_handle {
+    int base_ch;
+    int device;
+    // plans of the training forwards still awaiting their backward, keyed by workspace pointer
+    std::mutex mu;
+    std::vector<std::pair<void *, Plan>> live;
+    void remember(void *ws, const Plan &pl)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : live) if (e.first == ws) { e.second = pl; return; }
+        if (live.size() >= 16) live.erase(live.begin());
+        live.emplace_back(ws, pl);
+    }
+    bool lookup(void *ws, Plan &pl)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : live) if (e.first == ws) { pl = e.second; return true; }
+        return false;
+    }
+};
+
+namespace unet {
+
+static size_t layer_numel(int base, int layer, bool bias)
+{
+    const int c[5] = {base, base * 2, base * 4, base * 8, base * 16};
+    int ci, co, k;
+    bool up = false;
+    switch (layer) {
+    case C11C: ci = 1; co = c[0]; k = 3; break;
+    case C12C: ci = c[0]; co = c[0]; k = 3; break;
+    case C21C: ci = c[0]; co = c[1]; k = 3; break;
+    case C22C: ci = c[1]; co = c[1]; k = 3; break;
+    case C31C: ci = c[1]; co = c[2]; k = 3; break;
+    case C32C: ci = c[2]; co = c[2]; k = 3; break;
+    case C41C: ci = c[2]; co = c[3]; k = 3; break;
+    case C42C: ci = c[3]; co = c[3]; k = 3; break;
+    case C51C: ci = c[3]; co = c[4]; k = 3; break;
+    case C52C: ci = c[4]; co = c[4]; k = 3; break;
+    case UP4: ci = c[4]; co = c[3]; k = 2; up = true; break;
+    case C41E: ci = c[4]; co = c[3]; k = 3; break;
+    case C42E: ci = c[3]; co = c[3]; k = 3; break;
+    case UP3: ci = c[3]; co = c[2]; k = 2; up = true; break;
+    case C31E: ci = c[3]; co = c[2]; k = 3; break;
+    case C32E: ci = c[2]; co = c[2]; k = 3; break;
+    case UP2: ci = c[2]; co = c[1]; k = 2; up = true; break;
+    case C21E: ci = c[2]; co = c[1]; k = 3; break;
+    case C22E: ci = c[1]; co = c[1]; k = 3; break;
+    case UP1: ci = c[1]; co = c[0]; k = 2; up = true; break;
+    case C11E: ci = c[1]; co = c[0]; k = 3; break;
+    case C12E: ci = c[0]; co = c[0]; k = 3; break;
+    default: ci = c[0]; co = 2; k = 1; break;
+    }
+    (void)up;
+    return bias ? (size_t)co : (size_t)ci * co * k * k;
+}
+
+static int check_size(int S)
+{
+    if (S < 60 + 16 * 8 || (S - 60) % 16 != 0 || ((S - 60) / 16) % 2 != 0) {
+        set_error("input size %d is not 16L+60 with L even >= 8: the reference's crop_and_concat/torch.cat "
+                  "raises on it (network.py:124-127)", S);
+        return UNET_E_BADSIZE;
+    }
+    return 0;
+}
+
+// ---- descriptor builders (shared by the plan sizing and the launches) ----------------------------
+static IgemmP conv_fwd_desc(const float *x1, int H1, int W1, int C1, int pad1, const float *x2, int C2,
+                            int B, int H, int W, const float *wt, const float *bias, int K, int relu, float *y)
+{
+    IgemmP p{};
+    p.nsrc = x2 ? 2 : 1;
+    p.src[0] = GSrc{x1, H1, W1, C1, 0, C1, pad1};
+    if (x2) p.src[1] = GSrc{x2, H, W, C2, 0, C2, 0};
+    p.wt = wt; p.Kd = 9 * (C1 + C2);
+    p.T = 9; p.TX = 3; p.stride = 1; p.oy0 = 0; p.ox0 = 0;
+    p.NB = B; p.OH = H - 2; p.OW = W - 2; p.M = B * p.OH * p.OW; p.Nn = K;
+    p.dst = y; p.DH = p.OH; p.DW = p.OW; p.DC = K; p.dn0 = 0;
+    p.bias = bias; p.relu = relu;
+    return p;
+}
+
+// dgrad of a 3x3 valid conv: dx over the window [oy0, oy0+OHW) of the conv's (virtual) input
+static IgemmP conv_dgrad_desc(const float *dz, int Ho, int Wo, int K, int B, int OHW, int o0,
+                              const float *wt_rows, int Nn, float *dx, const float *mask, const float *add)
+{
+    IgemmP p{};
+    p.nsrc = 1;
+    p.src[0] = GSrc{dz, Ho, Wo, K, 0, K, 2};
+    p.wt = wt_rows; p.Kd = 9 * K;
+    p.T = 9; p.TX = 3; p.stride = 1; p.oy0 = o0; p.ox0 = o0;
+    p.NB = B; p.OH = OHW; p.OW = OHW; p.M = B * OHW * OHW; p.Nn = Nn;
+    p.dst = dx; p.DH = OHW; p.DW = OHW; p.DC = Nn; p.dn0 = 0;
+    p.mask = mask; p.add = add;
+    return p;
+}
+
+static WgradP conv_wgrad_desc(const float *X, int XH, int XC, int xpad, const float *dz, int Ho, int K, int B,
+                              float *dw, int Ctot, int c_off, float *slab, size_t slab_bytes)
+{
+    WgradP p{};
+    p.X = X; p.XH = XH; p.XW = XH; p.XC = XC; p.xc0 = 0; p.xpad = xpad;
+    p.Y = dz; p.YH = Ho; p.YW = Ho; p.YC = K; p.yc0 = 0;
+    p.NB = B; p.stride = 1; p.TY = 3; p.TX = 3; p.oy0 = 0; p.ox0 = 0;
+    int w0 = xpad - 2; if (w0 < 0) w0 = 0;
+    int w1 = xpad + XH; if (w1 > Ho) w1 = Ho;
+    p.ywin0 = w0; p.ywin1 = w1; p.xwin0 = w0; p.xwin1 = w1;
+    p.Ci = XC; p.Cj = K;
+    p.out = dw ? dw + (size_t)c_off * 9 : nullptr; p.si = 9; p.sj = (long)Ctot * 9; p.st = 1;
+    p.slab = slab; p.slab_bytes = slab_bytes;
+    return p;
+}
+
+static WgradP upconv_wgrad_desc(const float *x, int H, int Ci, const float *dy, int Co, int B, float *dw,
+                                float *slab, size_t slab_bytes)
+{
+    WgradP p{};
+    p.X = dy; p.XH = 2 * H; p.XW = 2 * H; p.XC = Co; p.xc0 = 0; p.xpad = 0;
+    p.Y = x; p.YH = H; p.YW = H; p.YC = Ci; p.yc0 = 0;
+    p.NB = B; p.stride = 2; p.TY = 2; p.TX = 2; p.oy0 = 0; p.ox0 = 0;
+    p.ywin0 = 0; p.ywin1 = H; p.xwin0 = 0; p.xwin1 = H;
+    p.Ci = Co; p.Cj = Ci;
+    p.out = dw; p.si = 4; p.sj = (long)Co * 4; p.st = 1;
+    p.slab = slab; p.slab_bytes = slab_bytes;
+    return p;
+}
+
+static int make_plan(Plan &pl, int base, int B, int S, int training)
+{
+    int rc = check_size(S);
+    if (rc) return rc;
+    if (B <= 0) { set_error("batch must be positive"); return UNET_E_BADARG; }
+    pl = Plan();
+    pl.B = B; pl.S = S; pl.base = base; pl.training = training;
+    for (int l = 0; l < 5; ++l) pl.ch[l] = base << l;
+    int cur = S;
+    for (int l = 0; l < 5; ++l) {
+        pl.ein[l] = cur; pl.ea1[l] = cur - 2; pl.ea2[l] = cur - 4;
+        if (l < 4) { pl.et[l] = pl.ea2[l] / 2; cur = pl.et[l]; }
+    }
+    int d = pl.ea2[4];
+    for (int l = 3; l >= 0; --l) {
+        pl.eu[l] = 2 * d; pl.pad[l] = (pl.eu[l] - pl.et[l]) / 2;
+        if (pl.pad[l] < 0 || (pl.eu[l] - pl.et[l]) % 2) { set_error("internal: skip geometry"); return UNET_E_BADSIZE; }
+        pl.ed1[l] = pl.eu[l] - 2; pl.ed2[l] = pl.eu[l] - 4; d = pl.ed2[l];
+    }
+    pl.So = d;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    auto sq = [&](int e, int c) { return (size_t)B * e * e * c; };
+    for (int l = 0; l < 5; ++l) { pl.a1[l] = take(sq(pl.ea1[l], pl.ch[l])); pl.a2[l] = take(sq(pl.ea2[l], pl.ch[l])); }
+    for (int l = 0; l < 4; ++l) {
+        pl.t[l] = take(sq(pl.et[l], pl.ch[l])); pl.u[l] = take(sq(pl.eu[l], pl.ch[l]));
+        pl.d1[l] = take(sq(pl.ed1[l], pl.ch[l])); pl.d2[l] = take(sq(pl.ed2[l], pl.ch[l]));
+    }
+    for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wt_fwd[i] = take(layer_numel(base, i, false));
+    if (training) {
+        pl.xin = take((size_t)B * S * S);
+        for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wt_bwd[i] = take(layer_numel(base, i, false));
+        for (int l = 0; l < 5; ++l) { pl.g_a1[l] = take(sq(pl.ea1[l], pl.ch[l])); pl.g_a2[l] = take(sq(pl.ea2[l], pl.ch[l])); }
+        for (int l = 0; l < 4; ++l) {
+            pl.g_t[l] = take(sq(pl.et[l], pl.ch[l])); pl.g_ts[l] = take(sq(pl.et[l], pl.ch[l]));
+            pl.g_u[l] = take(sq(pl.eu[l], pl.ch[l]));
+            pl.g_d1[l] = take(sq(pl.ed1[l], pl.ch[l])); pl.g_d2[l] = take(sq(pl.ed2[l], pl.ch[l]));
+        }
+        // split-K slab: the largest need over all weight-gradient launches
+        size_t need = 0;
+        auto upd = [&](const WgradP &w) { size_t n = wgrad_slab_need(w); if (n > need) need = n; };
+        if (base % 64 == 0) {
+            for (int l = 0; l < 5; ++l) {
+                if (l > 0) upd(conv_wgrad_desc(nullptr, pl.ein[l], pl.ch[l - 1], 0, nullptr, pl.ea1[l], pl.ch[l], B, nullptr, pl.ch[l - 1], 0, nullptr, 0));
+                upd(conv_wgrad_desc(nullptr, pl.ea1[l], pl.ch[l], 0, nullptr, pl.ea2[l], pl.ch[l], B, nullptr, pl.ch[l], 0, nullptr, 0));
+            }
+            for (int l = 0; l < 4; ++l) {
+                upd(conv_wgrad_desc(nullptr, pl.et[l], pl.ch[l], pl.pad[l], nullptr, pl.ed1[l], pl.ch[l], B, nullptr, 2 * pl.ch[l], 0, nullptr, 0));
+                upd(conv_wgrad_desc(nullptr, pl.eu[l], pl.ch[l], 0, nullptr, pl.ed1[l], pl.ch[l], B, nullptr, 2 * pl.ch[l], 0, nullptr, 0));
+                upd(conv_wgrad_desc(nullptr, pl.ed1[l], pl.ch[l], 0, nullptr, pl.ed2[l], pl.ch[l], B, nullptr, pl.ch[l], 0, nullptr, 0));
+                upd(upconv_wgrad_desc(nullptr, pl.eu[l] / 2, pl.ch[l + 1], nullptr, pl.ch[l], B, nullptr, nullptr, 0));
+            }
+        }
+        pl.slab_bytes = need;
+        pl.slab = take(need / sizeof(float));
+        // small scratch: bias-grad partials, conv11c / head partials
+        size_t sm = 0;
+        auto upds = [&](size_t n) { if (n > sm) sm = n; };
+        for (int l = 0; l < 5; ++l) { upds(bias_grad_scratch_bytes(sq(pl.ea1[l], 1), pl.ch[l])); upds(bias_grad_scratch_bytes(sq(pl.ea2[l], 1), pl.ch[l])); }
+        for (int l = 0; l < 4; ++l) { upds(bias_grad_scratch_bytes(sq(pl.eu[l], 1), pl.ch[l])); upds(bias_grad_scratch_bytes(sq(pl.ed1[l], 1), pl.ch[l])); }
+        upds(unet_conv1ch_bwd_scratch_bytes(B, S, base));
+        upds(unet_head1x1_bwd_scratch_bytes(B, pl.So, pl.So, base));
+        pl.small_bytes = sm;
+        pl.small = take(sm / sizeof(float) + 1);
+    }
+    pl.total = off;
+    return 0;
+}
+
+}  // namespace unet
+
+// =================================================================================================
+extern "C" {
+
+const char *unet_last_error(void) { return g_err; }
+int unet_abi_version(void) { return 1; }
+
+int unet_create(unet_handle **out, const unet_config *cfg)
+{
+    ARG_CHECK(out && cfg, "unet_create: null argument");
+    ARG_CHECK(cfg->base_ch == 64 || cfg->base_ch == 32, "unet_create: base_ch %d unsupported (32 or 64)", cfg->base_ch);
+    HIP_TRY(hipSetDevice(cfg->device));
+    if (!zero_page()) return UNET_E_BADARG;
+    unet_handle *h = new unet_handle();
+    h->base_ch = cfg->base_ch;
+    h->device = cfg->device;
+    *out = h;
+    return 0;
+}
+
+int unet_destroy(unet_handle *h)
+{
+    delete h;
+    return 0;
+}
+
+int unet_output_size(int S, int *out_size)
+{
+    int rc = check_size(S);
+    if (rc) return rc;
+    if (out_size) *out_size = S - 184;
+    return 0;
+}
+
+int unet_param_count(const unet_handle *h, int idx, size_t *numel)
+{
+    ARG_CHECK(h && numel && idx >= 0 && idx < UNET_N_PARAMS, "unet_param_count: bad argument");
+    *numel = layer_numel(h->base_ch, idx / 2, idx & 1);
+    return 0;
+}
+
+size_t unet_workspace_bytes(const unet_handle *h, int B, int S, int training)
+{
+    if (!h) { set_error("null handle"); return 0; }
+    Plan pl;
+    if (make_plan(pl, h->base_ch, B, S, training)) return 0;
+    return pl.total;
+}
+
+double unet_flops(const unet_handle *h, int B, int S, int backward)
+{
+    if (!h) return 0.0;
+    Plan pl;
+    if (make_plan(pl, h->base_ch, B, S, 0)) return 0.0;
+    double f = 0.0, f11c = 0.0;
+    auto conv = [&](int eo, int ci, int co, int k) { return 2.0 * B * (double)eo * eo * ci * co * k * k; };
+    for (int l = 0; l < 5; ++l) {
+        const int ci = l ? pl.ch[l - 1] : 1;
+        const double a = conv(pl.ea1[l], ci, pl.ch[l], 3);
+        if (l == 0) f11c = a;
+        f += a + conv(pl.ea2[l], pl.ch[l], pl.ch[l], 3);
+    }
+    for (int l = 0; l < 4; ++l) {
+        f += 2.0 * B * (double)(pl.eu[l] / 2) * (pl.eu[l] / 2) * pl.ch[l + 1] * pl.ch[l] * 4;   // up-conv
+        f += conv(pl.ed1[l], 2 * pl.ch[l], pl.ch[l], 3) + conv(pl.ed2[l], pl.ch[l], pl.ch[l], 3);
+    }
+    f += conv(pl.So, pl.ch[0], 2, 1);
+    return backward ? 3.0 * f - f11c : f;      // bwd = dgrad + wgrad, conv11c needs no dgrad (A23)
+}
+
+#define WS(off) ((float *)((char *)workspace + (off)))
+#define PARAM(i) ((const float *)params[(i)])
+
+int unet_forward(unet_handle *h, const void *const *params, const void *x, void *logits, int B, int S,
+                 void *workspace, size_t workspace_bytes, int training, void *stream)
+{
+    ARG_CHECK(h && params && x && logits && workspace, "unet_forward: null argument");
+    Plan pl;
+    int rc = make_plan(pl, h->base_ch, B, S, training);
+    if (rc) return rc;
+    ARG_CHECK(workspace_bytes >= pl.total, "unet_forward: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+    ARG_CHECK(((uintptr_t)workspace & 255) == 0, "unet_forward: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int *ch = pl.ch;
+
+    // repack the parameters (reference layout, owned by the caller and updated by its optimizer)
+    for (int l = 1; l < 5; ++l) {
+        if ((rc = pack_conv_fwd(PARAM(2 * (2 * l)), WS(pl.wt_fwd[2 * l]), ch[l], ch[l - 1], 0, st))) return rc;
+    }
+    for (int l = 0; l < 5; ++l)
+        if ((rc = pack_conv_fwd(PARAM(2 * (2 * l + 1)), WS(pl.wt_fwd[2 * l + 1]), ch[l], ch[l], 0, st))) return rc;
+    for (int l = 0; l < 4; ++l) {
+        if ((rc = pack_upconv_fwd(PARAM(2 * UP_L[l]), WS(pl.wt_fwd[UP_L[l]]), ch[l + 1], ch[l], st))) return rc;
+        if ((rc = pack_conv_fwd(PARAM(2 * C1E_L[l]), WS(pl.wt_fwd[C1E_L[l]]), ch[l], ch[l], ch[l], st))) return rc;
+        if ((rc = pack_conv_fwd(PARAM(2 * C2E_L[l]), WS(pl.wt_fwd[C2E_L[l]]), ch[l], ch[l], 0, st))) return rc;
+    }
+
+    // encoder (network.py:131-156); the input is kept for conv11c's weight gradient
+    if (training) HIP_TRY(hipMemcpyAsync(WS(pl.xin), x, (size_t)B * S * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = unet_conv1ch_fwd(x, B, S, PARAM(0), PARAM(1), ch[0], WS(pl.a1[0]), stream))) return rc;
+    for (int l = 0; l < 5; ++l) {
+        if (l > 0) {
+            IgemmP p = conv_fwd_desc(WS(pl.t[l - 1]), pl.ein[l], pl.ein[l], ch[l - 1], 0, nullptr, 0, B, pl.ein[l], pl.ein[l],
+                                     WS(pl.wt_fwd[2 * l]), PARAM(2 * (2 * l) + 1), ch[l], 1, WS(pl.a1[l]));
+            if ((rc = launch_igemm(p, st))) return rc;
+        }
+        IgemmP p = conv_fwd_desc(WS(pl.a1[l]), pl.ea1[l], pl.ea1[l], ch[l], 0, nullptr, 0, B, pl.ea1[l], pl.ea1[l],
+                                 WS(pl.wt_fwd[2 * l + 1]), PARAM(2 * (2 * l + 1) + 1), ch[l], 1, WS(pl.a2[l]));
+        if ((rc = launch_igemm(p, st))) return rc;
+        if (l < 4 && (rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
+    }
+    // decoder (network.py:159-188): up-conv, virtual zero-pad-concat, two convs
+    const float *dsrc = WS(pl.a2[4]);
+    for (int l = 3; l >= 0; --l) {
+        const int hin = pl.eu[l] / 2;
+        IgemmP u{};
+        u.nsrc = 1; u.src[0] = GSrc{dsrc, hin, hin, ch[l + 1], 0, ch[l + 1], 0};
+        u.wt = WS(pl.wt_fwd[UP_L[l]]); u.Kd = ch[l + 1];
+        u.T = 1; u.TX = 1; u.stride = 1;
+        u.NB = B; u.OH = hin; u.OW = hin; u.M = B * hin * hin; u.Nn = 4 * ch[l];
+        u.dst = WS(pl.u[l]); u.DH = pl.eu[l]; u.DW = pl.eu[l]; u.DC = ch[l]; u.scatter = 1; u.cout = ch[l];
+        u.bias = PARAM(2 * UP_L[l] + 1);
+        if ((rc = launch_igemm(u, st))) return rc;
+        IgemmP c1 = conv_fwd_desc(WS(pl.t[l]), pl.et[l], pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l], pl.eu[l],
+                                  WS(pl.wt_fwd[C1E_L[l]]), PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]));
+        if ((rc = launch_igemm(c1, st))) return rc;
+        IgemmP c2 = conv_fwd_desc(WS(pl.d1[l]), pl.ed1[l], pl.ed1[l], ch[l], 0, nullptr, 0, B, pl.ed1[l], pl.ed1[l],
+                                  WS(pl.wt_fwd[C2E_L[l]]), PARAM(2 * C2E_L[l] + 1), ch[l], 1, WS(pl.d2[l]));
+        if ((rc = launch_igemm(c2, st))) return rc;
+        dsrc = WS(pl.d2[l]);
+    }
+    if ((rc = unet_head1x1_fwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), PARAM(2 * FINAL + 1), logits, stream))) return rc;
+    if (training) h->remember(workspace, pl);
+    return 0;
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+// Stage order = reverse layer order, so gradient buckets complete early for the all-reduce:
+//   0: finalconv, conv12e, conv11e, upconv1      1: conv22e, conv21e, upconv2
+//   2: conv32e, conv31e, upconv3                 3: conv42e, conv41e, upconv4
+//   4: conv52c, conv51c                          5: conv42c ... conv11c
+static const int N_STAGES = 6;
+int unet_backward_stages(void) { return N_STAGES; }
+
+int unet_backward_stage_params(int stage, int *idx, int cap)
+{
+    int layers[12], n = 0;
+    if (stage >= 0 && stage < 4) {
+        const int l = stage;
+        if (l == 0) layers[n++] = FINAL;
+        layers[n++] = C2E_L[l]; layers[n++] = C1E_L[l]; layers[n++] = UP_L[l];
+    } else if (stage == 4) {
+        layers[n++] = C52C; layers[n++] = C51C;
+    } else if (stage == 5) {
+        for (int l = C42C; l >= C11C; --l) layers[n++] = l;
+    }
+    int k = 0;
+    for (int i = 0; i < n; ++i)
+        for (int b = 0; b < 2; ++b)
+            if (k < cap && idx) idx[k++] = 2 * layers[i] + b; else if (!idx || k >= cap) ++k;
+    return 2 * n;
+}
+
+#define GRAD(i) ((float *)grads[(i)])
+
+static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const void *const *params, void *const *grads,
+                         int layer, const float *X, int XH, int C, const float *dz, int Ho, int K,
+                         float *dx, const float *mask, const float *add)
+{
+    // single-source 3x3 conv: dgrad (optional), wgrad, bias grad
+    const int B = pl.B;
+    int rc;
+    if (dx) {
+        if ((rc = pack_conv_dgrad(PARAM(2 * layer), WS(pl.wt_bwd[layer]), K, C, st))) return rc;
+        IgemmP d = conv_dgrad_desc(dz, Ho, Ho, K, B, XH, 0, WS(pl.wt_bwd[layer]), C, dx, mask, add);
+        if ((rc = launch_igemm(d, st))) return rc;
+    }
+    WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes);
+    if ((rc = launch_wgrad(w, st))) return rc;
+    return bias_grad(dz, (size_t)B * Ho * Ho, K, GRAD(2 * layer + 1), WS(pl.small), st);
+}
+
+int unet_backward_stage(unet_handle *h, int stage, const void *const *params, const void *dlogits, void *const *grads,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    ARG_CHECK(h && params && grads && workspace, "unet_backward: null argument");
+    Plan pl;
+    if (!h->lookup(workspace, pl)) {
+        set_error("unet_backward: no training forward has been run on this workspace");
+        return UNET_E_NOTREADY;
+    }
+    ARG_CHECK(workspace_bytes >= pl.total, "unet_backward: workspace too small");
+    if (pl.base % 64 != 0) { set_error("unet_backward: base_ch %d unsupported for training (needs a multiple of 64)", pl.base); return UNET_E_UNSUPPORTED; }
+    ARG_CHECK(stage >= 0 && stage < N_STAGES, "unet_backward: bad stage %d", stage);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = pl.B;
+    const int *ch = pl.ch;
+    int rc;
+
+    if (stage < 4) {
+        const int l = stage;
+        if (l == 0) {
+            ARG_CHECK(dlogits, "unet_backward: null dlogits");
+            // finalconv backward, fused with the ReLU backward of conv12e -> dz of conv12e
+            if ((rc = unet_head1x1_bwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), dlogits, WS(pl.g_d2[0]),
+                                       GRAD(2 * FINAL), GRAD(2 * FINAL + 1), WS(pl.small), stream))) return rc;
+        }
+        // conv_l2e: input d1[l] (ReLU output of conv_l1e)
+        if ((rc = conv_backward(pl, workspace, st, params, grads, C2E_L[l], WS(pl.d1[l]), pl.ed1[l], ch[l], WS(pl.g_d2[l]), pl.ed2[l], ch[l],
+                                WS(pl.g_d1[l]), WS(pl.d1[l]), nullptr))) return rc;
+        // conv_l1e: virtual concat input.  dgrad per source half (skip half only over the crop window)
+        const int lay = C1E_L[l];
+        if ((rc = pack_conv_dgrad(PARAM(2 * lay), WS(pl.wt_bwd[lay]), ch[l], 2 * ch[l], st))) return rc;
+        {
+            IgemmP ds = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.et[l], pl.pad[l],
+                                        WS(pl.wt_bwd[lay]), ch[l], WS(pl.g_ts[l]), nullptr, nullptr);
+            if ((rc = launch_igemm(ds, st))) return rc;
+            IgemmP du = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.eu[l], 0,
+                                        WS(pl.wt_bwd[lay]) + (size_t)ch[l] * 9 * ch[l], ch[l], WS(pl.g_u[l]), nullptr, nullptr);
+            if ((rc = launch_igemm(du, st))) return rc;
+        }
+        {
+            WgradP ws_ = conv_wgrad_desc(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
+                                         GRAD(2 * lay), 2 * ch[l], 0, WS(pl.slab), pl.slab_bytes);
+            if ((rc = launch_wgrad(ws_, st))) return rc;
+            WgradP wu = conv_wgrad_desc(WS(pl.u[l]), pl.eu[l], ch[l], 0, WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
+                                        GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes);
+            if ((rc = launch_wgrad(wu, st))) return rc;
+            if ((rc = bias_grad(WS(pl.g_d1[l]), (size_t)B * pl.ed1[l] * pl.ed1[l], ch[l], GRAD(2 * lay + 1), WS(pl.small), st))) return rc;
+        }
+        // upconv_l: input is d2[l+1] (or a2[4]); its dgrad is masked by that ReLU output
+        {
+            const int ul = UP_L[l];
+            const int hin = pl.eu[l] / 2;
+            const float *uin = l == 3 ? WS(pl.a2[4]) : WS(pl.d2[l + 1]);
+            float *dzin = l == 3 ? WS(pl.g_a2[4]) : WS(pl.g_d2[l + 1]);
+            if ((rc = pack_upconv_dgrad(PARAM(2 * ul), WS(pl.wt_bwd[ul]), ch[l + 1], ch[l], st))) return rc;
+            IgemmP d{};
+            d.nsrc = 1; d.src[0] = GSrc{WS(pl.g_u[l]), pl.eu[l], pl.eu[l], ch[l], 0, ch[l], 0};
+            d.wt = WS(pl.wt_bwd[ul]); d.Kd = 4 * ch[l];
+            d.T = 4; d.TX = 2; d.stride = 2;
+            d.NB = B; d.OH = hin; d.OW = hin; d.M = B * hin * hin; d.Nn = ch[l + 1];
+            d.dst = dzin; d.DH = hin; d.DW = hin; d.DC = ch[l + 1];
+            d.mask = uin;
+            if ((rc = launch_igemm(d, st))) return rc;
+            WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes);
+            if ((rc = launch_wgrad(w, st))) return rc;
+            if ((rc = bias_grad(WS(pl.g_u[l]), (size_t)B * pl.eu[l] * pl.eu[l], ch[l], GRAD(2 * ul + 1), WS(pl.small), st))) return rc;
+        }
+        return 0;
+    }
+
+    if (stage == 4) {
+        if ((rc = conv_backward(pl, workspace, st, params, grads, C52C, WS(pl.a1[4]), pl.ea1[4], ch[4], WS(pl.g_a2[4]), pl.ea2[4], ch[4],
+                                WS(pl.g_a1[4]), WS(pl.a1[4]), nullptr))) return rc;
+        if ((rc = conv_backward(pl, workspace, st, params, grads, C51C, WS(pl.t[3]), pl.ein[4], ch[3], WS(pl.g_a1[4]), pl.ea1[4], ch[4],
+                                WS(pl.g_t[3]), nullptr, WS(pl.g_ts[3])))) return rc;
+        return unet_maxpool2_bwd(WS(pl.a2[3]), WS(pl.g_t[3]), WS(pl.g_a2[3]), B, pl.ea2[3], pl.ea2[3], ch[3], stream);
+    }
+
+    // stage 5: encoder levels 3..0
+    for (int l = 3; l >= 0; --l) {
+        if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l + 1, WS(pl.a1[l]), pl.ea1[l], ch[l], WS(pl.g_a2[l]), pl.ea2[l], ch[l],
+                                WS(pl.g_a1[l]), WS(pl.a1[l]), nullptr))) return rc;
+        if (l == 0) {
+            // conv11c: weight/bias gradient only (A1 needs no dgrad)
+            return unet_conv1ch_bwd(WS(pl.xin), B, pl.S, ch[0], WS(pl.g_a1[0]), GRAD(0), GRAD(1), WS(pl.small), stream);
+        }
+        if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l, WS(pl.t[l - 1]), pl.ein[l], ch[l - 1], WS(pl.g_a1[l]), pl.ea1[l], ch[l],
+                                WS(pl.g_t[l - 1]), nullptr, WS(pl.g_ts[l - 1])))) return rc;
+        if ((rc = unet_maxpool2_bwd(WS(pl.a2[l - 1]), WS(pl.g_t[l - 1]), WS(pl.g_a2[l - 1]), B, pl.ea2[l - 1], pl.ea2[l - 1], ch[l - 1], stream))) return rc;
+    }
+    return 0;
+}
+
+int unet_backward(unet_handle *h, const void *const *params, const void *dlogits, void *const *grads,
+                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    for (int s = 0; s < N_STAGES; ++s) {
+        int rc = unet_backward_stage(h, s, params, dlogits, grads, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Upper bound of the split-K slab for the per-op entry point (the split of C into two sources and the
+// skip window are not known when the caller sizes its scratch): twice the larger full-window need.
+static size_t conv_bwd_slab_bound(int B, int H, int C, int K)
+{
+    size_t need = 0;
+    for (int ci = 64; ci <= (C + 63) / 64 * 64; ci *= 2) {
+        WgradP w = conv_wgrad_desc(nullptr, H, ci, 0, nullptr, H - 2, K, B, nullptr, ci, 0, nullptr, 0);
+        const size_t n = wgrad_slab_need(w);
+        if (n > need) need = n;
+    }
+    return align_up(2 * need, 256);
+}
+
+// ---- per-op entry points (unit tests) --------------------------------------------------------------
+size_t unet_conv3x3_scratch_bytes(int C, int K) { return align_up((size_t)K * C * 9 * sizeof(float), 256); }
+
+int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2, int B, int H, int W,
+                     const void *w_oihw, const void *bias, int K, int relu, void *y, void *scratch, void *stream)
+{
+    ARG_CHECK(x1 && w_oihw && y && scratch, "conv3x3_fwd: null argument");
+    ARG_CHECK(x2 || (H1 + 2 * pad1 == H && W1 + 2 * pad1 == W), "conv3x3_fwd: single source must match the input extent");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = pack_conv_fwd((const float *)w_oihw, (float *)scratch, K, C1, x2 ? C2 : 0, st);
+    if (rc) return rc;
+    IgemmP p = conv_fwd_desc((const float *)x1, H1, W1, C1, pad1, (const float *)x2, x2 ? C2 : 0, B, H, W,
+                             (const float *)scratch, (const float *)bias, K, relu, (float *)y);
+    return launch_igemm(p, st);
+}
+
+size_t unet_conv3x3_bwd_scratch_bytes(int B, int H, int W, int C, int K)
+{
+    return align_up((size_t)K * C * 9 * sizeof(float), 256) + conv_bwd_slab_bound(B, H, C, K) +
+           align_up(bias_grad_scratch_bytes((size_t)B * (H - 2) * (W - 2), K), 256);
+}
+
+int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2, int B, int H, int W,
+                     const void *w_oihw, int K, const void *dz, void *dx1, const void *mask1, const void *add1,
+                     void *dx2, const void *mask2, void *dw, void *db, void *scratch, void *stream)
+{
+    ARG_CHECK(x1 && w_oihw && dz && scratch, "conv3x3_bwd: null argument");
+    ARG_CHECK(H == W && H1 == W1, "conv3x3_bwd: square tiles only");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = C1 + (x2 ? C2 : 0);
+    const int Ho = H - 2;
+    float *wt = (float *)scratch;
+    const size_t wt_bytes = align_up((size_t)K * C * 9 * sizeof(float), 256);
+    const size_t slab_bytes = conv_bwd_slab_bound(B, H, C, K);
+    float *slab = (float *)((char *)scratch + wt_bytes);
+    float *small = (float *)((char *)scratch + wt_bytes + slab_bytes);
+    int rc;
+    if (dx1 || dx2) {
+        if ((rc = pack_conv_dgrad((const float *)w_oihw, wt, K, C, st))) return rc;
+        if (dx1) {
+            IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H1, pad1, wt, C1, (float *)dx1, (const float *)mask1, (const float *)add1);
+            if ((rc = launch_igemm(d, st))) return rc;
+        }
+        if (dx2 && x2) {
+            IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H, 0, wt + (size_t)C1 * 9 * K, C2, (float *)dx2, (const float *)mask2, nullptr);
+            if ((rc = launch_igemm(d, st))) return rc;
+        }
+    }
+    if (dw) {
+        WgradP w1 = conv_wgrad_desc((const float *)x1, H1, C1, pad1, (const float *)dz, Ho, K, B, (float *)dw, C, 0, slab, slab_bytes);
+        if ((rc = launch_wgrad(w1, st))) return rc;
+        if (x2) {
+            WgradP w2 = conv_wgrad_desc((const float *)x2, H, C2, 0, (const float *)dz, Ho, K, B, (float *)dw, C, C1, slab, slab_bytes);
+            if ((rc = launch_wgrad(w2, st))) return rc;
+        }
+    }
+    if (db && (rc = bias_grad((const float *)dz, (size_t)B * Ho * Ho, K, (float *)db, small, st))) return rc;
+    return 0;
+}
+
+size_t unet_upconv2_scratch_bytes(int B, int H, int W, int Ci, int Co)
+{
+    (void)W;
+    WgradP w = upconv_wgrad_desc(nullptr, H, Ci, nullptr, Co, B, nullptr, nullptr, 0);
+    return align_up((size_t)Ci * Co * 4 * sizeof(float), 256) + align_up(wgrad_slab_need(w), 256) +
+           align_up(bias_grad_scratch_bytes((size_t)B * 4 * H * W, Co), 256);
+}
+
+int unet_upconv2_fwd(const void *x, int B, int H, int W, int Ci, const void *w_iohw, const void *bias, int Co,
+                     void *y, void *scratch, void *stream)
+{
+    ARG_CHECK(x && w_iohw && y && scratch, "upconv2_fwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = pack_upconv_fwd((const float *)w_iohw, (float *)scratch, Ci, Co, st);
+    if (rc) return rc;
+    IgemmP u{};
+    u.nsrc = 1; u.src[0] = GSrc{(const float *)x, H, W, Ci, 0, Ci, 0};
+    u.wt = (const float *)scratch; u.Kd = Ci;
+    u.T = 1; u.TX = 1; u.stride = 1;
+    u.NB = B; u.OH = H; u.OW = W; u.M = B * H * W; u.Nn = 4 * Co;
+    u.dst = (float *)y; u.DH = 2 * H; u.DW = 2 * W; u.DC = Co; u.scatter = 1; u.cout = Co;
+    u.bias = (const float *)bias;
+    return launch_igemm(u, st);
+}
+
+int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_iohw, int Co, const void *dy,
+                     void *dx, const void *mask, void *dw, void *db, void *scratch, void *stream)
+{
+    ARG_CHECK(x && w_iohw && dy && scratch, "upconv2_bwd: null argument");
+    ARG_CHECK(H == W, "upconv2_bwd: square tiles only");
+    hipStream_t st = (hipStream_t)stream;
+    float *wt = (float *)scratch;
+    const size_t wt_bytes = align_up((size_t)Ci * Co * 4 * sizeof(float), 256);
+    WgradP sizing = upconv_wgrad_desc(nullptr, H, Ci, nullptr, Co, B, nullptr, nullptr, 0);
+    const size_t slab_bytes = align_up(wgrad_slab_need(sizing), 256);
+    float *slab = (float *)((char *)scratch + wt_bytes);
+    float *small = (float *)((char *)scratch + wt_bytes + slab_bytes);
+    int rc;
+    if (dx) {
+        if ((rc = pack_upconv_dgrad((const float *)w_iohw, wt, Ci, Co, st))) return rc;
+        IgemmP d{};
+        d.nsrc = 1; d.src[0] = GSrc{(const float *)dy, 2 * H, 2 * W, Co, 0, Co, 0};
+        d.wt = wt; d.Kd = 4 * Co;
+        d.T = 4; d.TX = 2; d.stride = 2;
+        d.NB = B; d.OH = H; d.OW = W; d.M = B * H * W; d.Nn = Ci;
+        d.dst = (float *)dx; d.DH = H; d.DW = W; d.DC = Ci;
+        d.mask = (const float *)mask;
+        if ((rc = launch_igemm(d, st))) return rc;
+    }
+    if (dw) {
+        WgradP w = upconv_wgrad_desc((const float *)x, H, Ci, (const float *)dy, Co, B, (float *)dw, slab, slab_bytes);
+        if ((rc = launch_wgrad(w, st))) return rc;
+    }
+    if (db && (rc = bias_grad((const float *)dy, (size_t)B * 4 * H * W, Co, (float *)db, small, st))) return rc;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// wgrad.hip — weight gradients on the fp32 matrix cores (autograd backward of the convs, A23).
+//
+//   D[t][i][j] = sum_{img,y,x} X[img][(y+oy0)*s + ty - xpad][(x+ox0)*s + tx - xpad][xc0+i] * Y[img][y][x][yc0+j]
+//
+// conv3x3  : X = layer input (NHWC, optionally the zero-padded skip tensor), Y = dz, s=1, 3x3 taps
+//            -> dW[k=j][c=i][ty][tx]                                     (network.py:23-56 weights)
+// up-conv  : X = dOut (stride-2 gather, 2x2 taps), Y = layer input, roles transposed
+//            -> dW[ci=j][co=i][a][b]                                     (network.py:38-53 weights)
+//
+// The reduction runs over pixels, the output is tiny, so the kernel is split-K: one workgroup owns
+// a 64(i) x 64(j) channel tile for ALL taps and a (image, row-chunk, column-strip) of pixels.  Per
+// output row it stages one Y row-strip and the s new X rows of the halo ring into LDS with
+// global_load_lds (the 3x3 taps then re-read the same LDS rows: X is fetched once, not 9x), and every
+// wave accumulates T 32x32 MFMA tiles (v_mfma_f32_32x32x2_f32, K = a pair of pixels).  Partial tiles
+// go to a slab and a second kernel reduces them in a fixed order (deterministic, no atomics).
+#include "common.hpp"
+
+namespace unet {
+
+#define GLDS16(gptr, lptr)                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+constexpr int PWMAX = 32;     // pixels per strip (MFMA K = pixel pairs)
+
+struct WgradK {               // kernel-side copy with the derived decomposition
+    WgradP p;
+    int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
+};
+
+template <int TY, int TX, int S>
+struct WgradGeom {
+    static constexpr int T = TY * TX;
+    static constexpr int XPX = ((PWMAX - 1) * S + TX + 3) / 4 * 4;   // staged X pixels per row
+    static constexpr int XGROUPS = XPX / 4;
+    static constexpr int YGROUPS = PWMAX / 4;
+    static constexpr int RING = 4;                                    // X row slots (>= TY + S)
+    static constexpr int XSLOT = XPX * 256;                           // bytes: 64 channels fp32 per pixel
+    static constexpr int YBUF = PWMAX * 256;
+    static constexpr int LDS = RING * XSLOT + 2 * YBUF;
+    static_assert(TY + S <= RING, "ring too small");
+};
+
+template <int TY, int TX, int S>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradK k)
+{
+    using G = WgradGeom<TY, TX, S>;
+    constexpr int T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xs = smem;
+    unsigned char *ys = smem + G::RING * G::XSLOT;
+    const WgradP &p = k.p;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+
+    // block -> (pixel partition P, channel tile); tiles of one partition are neighbours on one XCD
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int ntile = k.ntile_i * k.ntile_j;
+    const int P = logical / ntile;
+    const int tile = logical - P * ntile;
+    const int it = tile / k.ntile_j, jt = tile - it * k.ntile_j;
+    const int strip = P % k.nstrips;
+    const int pc = P / k.nstrips;
+    const int chunk = pc % k.nchunks;
+    const int img = pc / k.nchunks;
+
+    const int x0 = p.xwin0 + strip * k.pw;
+    int pwv = p.xwin1 - x0; pwv = pwv < k.pw ? pwv : k.pw;           // valid pixels in this strip
+    const int ya = p.ywin0 + chunk * k.rows_per_chunk;
+    int yb = ya + k.rows_per_chunk; yb = yb < p.ywin1 ? yb : p.ywin1;
+    const int npairs = (pwv + 1) >> 1;
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    const float *zsrc = p.zeros + 4 * l15;
+    const int xcol0 = (x0 + p.ox0) * S - p.xpad;
+
+    // stage one X row (global row xr of image img) into its ring slot, pixel group g
+    auto stage_x = [&](int xr, int g) {
+        const int px = 4 * g + lq;
+        const int xc = xcol0 + px;
+        const bool ok = (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW;
+        const float *src = p.X + ((size_t)((img * p.XH + xr) * p.XW + xc) * p.XC + p.xc0 + it * 64 + 4 * l15);
+        GLDS16(ok ? src : zsrc, xs + (xr & (G::RING - 1)) * G::XSLOT + g * 1024);
+    };
+    auto stage_y = [&](int y, int buf, int g) {
+        const int px = 4 * g + lq;
+        const bool ok = px < pwv;
+        const float *src = p.Y + ((size_t)((img * p.YH + y) * p.YW + x0 + px) * p.YC + p.yc0 + jt * 64 + 4 * l15);
+        GLDS16(ok ? src : zsrc, ys + buf * G::YBUF + g * 1024);
+    };
+    // items of one step: S new X rows (XGROUPS groups each) then the Y row; round-robin over waves
+    auto stage_step = [&](int y, int buf, int first_row, int nrows) {
+        const int xr_base = (y + p.oy0) * S - p.xpad;
+        const int nx = nrows * G::XGROUPS;
+        for (int e = wave; e < nx + G::YGROUPS; e += 4) {
+            if (e < nx) {
+                const int rr = e / G::XGROUPS;
+                stage_x(xr_base + first_row + rr, e - rr * G::XGROUPS);
+            } else {
+                stage_y(y, buf, e - nx);
+            }
+        }
+    };
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_lane = (wi * 32 + l31) * 4;      // byte offset of this lane's X channel within a pixel
+    const int b_lane = (wj * 32 + l31) * 4;
+
+    if (ya < yb) {
+        stage_step(ya, 0, 0, TY);                // prologue: all TY rows + Y row
+        __syncthreads();
+        for (int y = ya; y < yb; ++y) {
+            const int cur = (y - ya) & 1;
+            if (y + 1 < yb) stage_step(y + 1, cur ^ 1, TY - S, S);   // rows new to the next step
+            const int xr0 = (y + p.oy0) * S - p.xpad;
+            const unsigned char *yrow = ys + cur * G::YBUF + b_lane;
+            for (int q = 0; q < npairs; ++q) {
+                const int pix = 2 * q + lh;
+                const float b = *(const float *)(yrow + pix * 256);
+#pragma unroll
+                for (int ty = 0; ty < TY; ++ty) {
+                    const unsigned char *xrow = xs + ((xr0 + ty) & (G::RING - 1)) * G::XSLOT + a_lane;
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx) {
+                        const float a = *(const float *)(xrow + (pix * S + tx) * 256);
+                        acc[ty * TX + tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ty * TX + tx], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // partial tile -> slab[P][t][Ci][Cj]
+    float *slab = p.slab + (size_t)P * T * p.Ci * p.Cj;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = it * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int j = jt * 64 + wj * 32 + l31;
+            slab[((size_t)t * p.Ci + i) * p.Cj + j] = acc[t][r];
+        }
+    }
+}
+
+// out[i*si + j*sj + t*st] = sum_P slab[P][t][i][j]   (fixed summation order)
+__global__ void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, int T, int Ci, int Cj,
+                                    float *__restrict__ out, long si, long sj, long st)
+{
+    const size_t total = (size_t)T * Ci * Cj;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int P = 0;
+        for (; P + 4 <= nP; P += 4) {
+            s0 += slab[(size_t)P * total + e];
+            s1 += slab[(size_t)(P + 1) * total + e];
+            s2 += slab[(size_t)(P + 2) * total + e];
+            s3 += slab[(size_t)(P + 3) * total + e];
+        }
+        for (; P < nP; ++P) s0 += slab[(size_t)P * total + e];
+        const int j = (int)(e % Cj);
+        const size_t ti = e / Cj;
+        const int i = (int)(ti % Ci);
+        const int t = (int)(ti / Ci);
+        out[i * si + j * sj + t * st] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+static void decompose(const WgradP &p, WgradK &k)
+{
+    const int wx = p.xwin1 - p.xwin0, wy = p.ywin1 - p.ywin0;
+    k.nstrips = cdiv(wx, PWMAX);
+    int pw = cdiv(wx, k.nstrips);
+    pw = (pw + 1) & ~1;                       // even: MFMA K is a pixel pair
+    k.pw = pw;
+    k.nstrips = cdiv(wx, pw);
+    k.ntile_i = p.Ci / 64;
+    k.ntile_j = p.Cj / 64;
+    // aim for ~2048 workgroups, but at least 8 rows per workgroup to amortise the slab write
+    const long base = (long)p.NB * k.nstrips * k.ntile_i * k.ntile_j;
+    int nchunks = (int)((2048 + base - 1) / base);
+    if (nchunks < 1) nchunks = 1;
+    int rows = cdiv(wy, nchunks);
+    if (rows < 8) rows = wy < 8 ? wy : 8;
+    k.rows_per_chunk = rows;
+    k.nchunks = cdiv(wy, rows);
+}
+
+size_t wgrad_slab_need(const WgradP &p)
+{
+    WgradK k{};
+    decompose(p, k);
+    return (size_t)p.NB * k.nchunks * k.nstrips * p.TY * p.TX * p.Ci * p.Cj * sizeof(float);
+}
+
+static double wgrad_alg_flops(const WgradP &p)
+{
+    long cy = 0, cx = 0;
+    for (int y = 0; y < p.YH; ++y)
+        for (int t = 0; t < p.TY; ++t) { const int i = (y + p.oy0) * p.stride - p.xpad + t; cy += (i >= 0 && i < p.XH); }
+    for (int x = 0; x < p.YW; ++x)
+        for (int t = 0; t < p.TX; ++t) { const int i = (x + p.ox0) * p.stride - p.xpad + t; cx += (i >= 0 && i < p.XW); }
+    return 2.0 * p.NB * (double)cy * (double)cx * p.Ci * p.Cj;
+}
+
+template <int TY, int TX, int S>
+static int launch_wgrad_t(const WgradK &k, int nP, hipStream_t st)
+{
+    using G = WgradGeom<TY, TX, S>;
+    static bool attr_done = false;
+    auto kern = wgrad_f32_kernel<TY, TX, S>;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        attr_done = true;
+    }
+    prof_begin(1, wgrad_alg_flops(k.p), st);
+    hipLaunchKernelGGL(kern, dim3(nP * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_wgrad(WgradP p, hipStream_t st)
+{
+    ARG_CHECK(p.Ci % 64 == 0 && p.Cj % 64 == 0 && p.Ci > 0 && p.Cj > 0, "wgrad: channel tiles must be multiples of 64 (Ci=%d Cj=%d)", p.Ci, p.Cj);
+    ARG_CHECK(p.XC % 4 == 0 && p.YC % 4 == 0 && p.xc0 % 4 == 0 && p.yc0 % 4 == 0, "wgrad: channel pitch/offset must be multiples of 4");
+    ARG_CHECK(p.ywin0 >= 0 && p.ywin1 <= p.YH && p.xwin0 >= 0 && p.xwin1 <= p.YW && p.ywin0 < p.ywin1 && p.xwin0 < p.xwin1, "wgrad: bad window");
+    ARG_CHECK((size_t)p.NB * p.XH * p.XW * p.XC < 0x7FFFFFFFull * 2 && (size_t)p.NB * p.YH * p.YW * p.YC < 0x7FFFFFFFull * 2, "wgrad: tensor too large");
+    p.zeros = zero_page();
+    if (!p.zeros) return -2;
+    WgradK k{};
+    k.p = p;
+    decompose(p, k);
+    const int nP = p.NB * k.nchunks * k.nstrips;
+    const int T = p.TY * p.TX;
+    const size_t need = (size_t)nP * T * p.Ci * p.Cj * sizeof(float);
+    ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
+    int rc;
+    if (p.TY == 3 && p.TX == 3 && p.stride == 1) rc = launch_wgrad_t<3, 3, 1>(k, nP, st);
+    else if (p.TY == 2 && p.TX == 2 && p.stride == 2) rc = launch_wgrad_t<2, 2, 2>(k, nP, st);
+    else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
+    if (rc) return rc;
+    const size_t total = (size_t)T * p.Ci * p.Cj;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    prof_begin(2, 0.0, st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, nP, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace unet

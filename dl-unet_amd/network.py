@@ -1,0 +1,194 @@
+"""Drop-in for the reference's network.py: `from network import Unet`.
+
+Same class, constructor (no arguments), submodule names, 46 state-dict keys/shapes/layouts and call
+surface as the reference (network.py:8-192), but `forward` runs the hand-written HIP path for gfx950
+through the C ABI of libunet_hip.so (include/unet_hip.h) and backward is the library's own
+dgrad/wgrad kernels behind one torch.autograd.Function.  PyTorch supplies parameter storage,
+device memory, streams and (for data parallel) torch.distributed — nothing on the compute path.
+
+There is no CPU fallback: calling the module with a host tensor raises.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import _hip
+import dp as dp_mod
+
+_BASE = 64          # hard-coded in the reference (network.py:23-58)
+
+# (name, kind, cin, cout, k) in the reference's declaration order
+_LAYERS = [
+    ("conv11c", "conv", 1, 64, 3), ("conv12c", "conv", 64, 64, 3),
+    ("conv21c", "conv", 64, 128, 3), ("conv22c", "conv", 128, 128, 3),
+    ("conv31c", "conv", 128, 256, 3), ("conv32c", "conv", 256, 256, 3),
+    ("conv41c", "conv", 256, 512, 3), ("conv42c", "conv", 512, 512, 3),
+    ("conv51c", "conv", 512, 1024, 3), ("conv52c", "conv", 1024, 1024, 3),
+    ("upconv4", "up", 1024, 512, 2), ("conv41e", "conv", 1024, 512, 3), ("conv42e", "conv", 512, 512, 3),
+    ("upconv3", "up", 512, 256, 2), ("conv31e", "conv", 512, 256, 3), ("conv32e", "conv", 256, 256, 3),
+    ("upconv2", "up", 256, 128, 2), ("conv21e", "conv", 256, 128, 3), ("conv22e", "conv", 128, 128, 3),
+    ("upconv1", "up", 128, 64, 2), ("conv11e", "conv", 128, 64, 3), ("conv12e", "conv", 64, 64, 3),
+    ("finalconv", "conv", 64, 2, 1),
+]
+
+
+def _init_std(name, cin):
+    """std of the reference's weight re-initialisation (network.py:70-105).  As written there the
+    expression is 2 / sqrt(N) (operator precedence), N counted with 3x3 kernels
+    even for the up-convs and the 1x1 head; conv_k1e counts its two halves as C*9 + C*4."""
+    if name == "conv11c":
+        return 2 ** 0.5
+    if name.endswith("1e"):
+        half = cin // 2
+        return 2.0 / (half * 9 + half * 4) ** 0.5
+    return 2.0 / (cin * 9) ** 0.5
+
+
+_handles = {}
+
+
+def _handle(device_index):
+    h = _handles.get(device_index)
+    if h is None:
+        h = _hip.Handle(_BASE, device_index)
+        _handles[device_index] = h
+    return h
+
+
+def _stage_layout():
+    """Gradient flat-buffer order = completion order of the backward stages (reverse layer order),
+    so every stage's parameters form one contiguous bucket for the all-reduce."""
+    L = _hip.lib()
+    order, bounds = [], [0]
+    for s in range(L.unet_backward_stages()):
+        buf = (C.c_int * 64)()
+        n = L.unet_backward_stage_params(s, buf, 64)
+        order.extend(int(buf[i]) for i in range(n))
+        bounds.append(len(order))
+    return order, bounds
+
+
+class _UnetFunction(torch.autograd.Function):
+    """forward: unet_forward (replaces network.py:129-192); backward: unet_backward_stage x6
+    (replaces the autograd graph of every op in it), with an optional bucketed gradient all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        dev = x.device.index
+        h = _handle(dev)
+        B, _, S, _ = x.shape
+        nbytes = h.workspace_bytes(B, S, True)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        So = S - 184
+        logits = torch.empty(B, 2, So, So, dtype=torch.float32, device=x.device)
+        ptab = _hip.ptr_table(params)
+        _hip.check(_hip.lib().unet_forward(h.h, ptab, _hip.ptr(x), _hip.ptr(logits), B, S, _hip.ptr(ws), nbytes, 1,
+                                           _hip.stream()), "unet_forward")
+        ctx.save_for_backward(*params)
+        ctx.ws, ctx.nbytes, ctx.dev, ctx.module = ws, nbytes, dev, module
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        params = ctx.saved_tensors
+        module = ctx.module
+        h = _handle(ctx.dev)
+        L = _hip.lib()
+        buckets = module._buckets
+        flat, grads = buckets.allocate([p.shape for p in params], dlogits.device)
+        dp = module._dp
+        dlogits = dlogits.contiguous()
+        if dp is not None and dp[1] > 1:
+            dlogits = dlogits * (1.0 / dp[1])              # grads are linear in dlogits: SUM-reduce == mean
+        ptab, gtab = _hip.ptr_table(params), _hip.ptr_table(grads)
+        works = []
+        for s in range(buckets.n_stages()):
+            _hip.check(L.unet_backward_stage(h.h, s, ptab, _hip.ptr(dlogits), gtab, _hip.ptr(ctx.ws), ctx.nbytes,
+                                             _hip.stream()), "unet_backward_stage %d" % s)
+            if dp is not None and dp[1] > 1:
+                # RCCL all-reduce of this bucket on the communicator's stream, overlapping the next stage
+                works.append(buckets.reduce_stage(flat, s, dp[0]))
+        for w in works:
+            w.wait()
+        ctx.ws = None
+        return (None, None) + tuple(grads)
+
+
+class Unet(nn.Module):
+    """Unet 2D (Ronneberger et al. 2015) with the reference's exact structure and quirks:
+    valid 3x3 convs, skips taken AFTER the pool and zero-padded to the up-conv size,
+    1x1 head without activation; fp32; input [B,1,S,S] with S = 16L+60, L even."""
+
+    def __init__(self):
+        super(Unet, self).__init__()
+        # nn.Conv2d / nn.ConvTranspose2d serve ONLY as parameter containers with the reference's
+        # names, shapes and default-init RNG consumption (their forward is never called).
+        for name, kind, cin, cout, k in _LAYERS:
+            if kind == "conv":
+                setattr(self, name, nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=k))
+            else:
+                setattr(self, name, nn.ConvTranspose2d(in_channels=cin, out_channels=cout, kernel_size=k, stride=k))
+        # weights are then re-drawn in declaration order (network.py:70-105), biases keep the default
+        for name, kind, cin, cout, k in _LAYERS:
+            m = getattr(self, name)
+            m.weight = nn.Parameter(torch.empty_like(m.weight).normal_(mean=0, std=_init_std(name, cin)))
+        self._dp = None
+        self._buckets = None
+
+    # -- data parallel: batch-sharded replicas, gradients averaged with RCCL over xGMI -------------
+    def enable_data_parallel(self, process_group=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group)
+        self._dp = (process_group, world)
+        if world > 1:
+            with torch.no_grad():
+                for p in self.parameters():
+                    dist.broadcast(p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        return self
+
+    def _params(self):
+        out = []
+        for name, _, _, _, _ in _LAYERS:
+            m = getattr(self, name)
+            out.append(m.weight)
+            out.append(m.bias)
+        return out
+
+    def crop_and_concat(self, A, B):
+        """Public helper kept for API parity (network.py:108-127): crop (A larger) or ZERO-PAD (A
+        smaller, the case every valid input takes) A to B's extent and concatenate on channels.
+        The forward pass never materialises this tensor — the consuming conv reads both sources."""
+        crop_factor = (A.size()[2] - B.size()[2]) * 0.5
+        c = int(crop_factor)
+        A = F.pad(A, (-c, -c, -c, -c))
+        return torch.cat((A, B), 1)
+
+    def forward(self, t):
+        if not t.is_cuda:
+            raise RuntimeError("Unet.forward: the HIP path needs the input on a HIP device (got %s); "
+                               "there is no CPU fallback — use unet.to('cuda:0') and images.to('cuda:0')" % t.device)
+        if t.dim() != 4 or t.shape[1] != 1 or t.shape[2] != t.shape[3]:
+            raise RuntimeError("Unet.forward: expected input [B,1,S,S], got %s" % (tuple(t.shape),))
+        if t.dtype != torch.float32:
+            raise RuntimeError("Unet.forward: expected float32 input, got %s" % t.dtype)
+        if t.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the input image is not implemented (conv11c needs no dgrad)")
+        t = t.contiguous()
+        params = self._params()
+        if self._buckets is None:
+            order, bounds = _stage_layout()
+            self._buckets = dp_mod.GradBuckets([p.numel() for p in params], order, bounds)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _UnetFunction.apply(t, self, *params)
+        # inference (trainer.py:95 no_grad): no activation-gradient storage
+        h = _handle(t.device.index)
+        B, _, S, _ = t.shape
+        nbytes = h.workspace_bytes(B, S, False)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+        logits = torch.empty(B, 2, S - 184, S - 184, dtype=torch.float32, device=t.device)
+        _hip.check(_hip.lib().unet_forward(h.h, _hip.ptr_table([p.detach() for p in params]), _hip.ptr(t), _hip.ptr(logits),
+                                           B, S, _hip.ptr(ws), nbytes, 0, _hip.stream()), "unet_forward")
+        return logits

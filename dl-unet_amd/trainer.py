@@ -1,0 +1,159 @@
+"""Drop-in for the reference's trainer.py: `from trainer import training`, same signature
+(trainer.py:15) and epoch bookkeeping; the step body runs on the HIP path:
+
+    forward            unet(images)                        -> libunet_hip unet_forward
+    loss (L1)          BCEWithLogitsLoss(weight=class map)  -> unet_bce_logits (fwd + grad in one pass)
+    backward           loss.backward()                     -> unet_backward_stage x6 (+ RCCL all-reduce if DP)
+    update (L3)        SGD(lr=1e-4, momentum=0.99)          -> unet_sgd_momentum
+    prediction (L2)    preds.argmax(dim=1)                 -> unet_argmax2
+
+Reference behaviours kept on purpose: Q3 the dataset-name comparisons are identity
+tests in the reference and are False for names arriving from argv, so no stop goal is armed and
+class_balance is always used; Q4 the [B,H,W] weight map is right-aligned against [B,2,H,W]
+(works for B in {1,2}, raises otherwise); Q5 only the first sample's metrics are kept per epoch.
+"""
+import os
+from time import time
+
+import numpy as np
+import torch
+
+from functions import class_balance, evaluation_metrics
+import optim as hip_optim
+
+
+def maybe_mkdir_p(path):
+    os.makedirs(path, exist_ok=True)
+
+
+def _goal_for(DATASET):
+    # the reference compares with `is` against string literals (trainer.py:18-27); for a name built
+    # at run time (sys.argv) that is False, which leaves when_to_stop = None.  Reproduced as such.
+    return None, None
+
+
+def _step_loss(unet, images, labels, device, train):
+    preds = unet(images.to(device))
+    pad = int((preds.shape[-1] - labels.shape[-1]) / 2)
+    preds = preds[:, :, pad:labels.shape[-1] + pad, pad:labels.shape[-1] + pad]
+    ll = hip_optim.onehot2(labels, preds)                       # [1-y, y] (trainer.py:63-66)
+    weight_maps = class_balance(labels.squeeze(1)).to(device)   # [B,H,W] (trainer.py:72)
+    loss = hip_optim.bce_with_logits(preds, ll, weight=weight_maps)
+    return preds, loss
+
+
+def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_dir, DATASET):
+    when_to_stop, goal = _goal_for(DATASET)
+
+    optimizer = hip_optim.SGD(unet.parameters(), lr=0.0001, momentum=0.99)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.1, patience=30,
+                                                           threshold=1e-3, threshold_mode='rel', eps=1e-7)
+    my_patience = 0
+
+    maybe_mkdir_p(os.path.join(fold_dir, 'progress'))
+    maybe_mkdir_p(os.path.join(fold_dir, 'models'))
+
+    loss_best_epoch = 100000.0
+    progress = {k: None for k in ('train_iou', 'train_pe', 'val_iou', 'val_pe', 'loss', 'loss_val')}
+
+    for epoch in range(epochs + 1):
+        print(' ')
+        print('Epoch:', epoch)
+        start = time()
+        total_loss = 0
+        total_loss_val = 0
+        train_eval = None
+        val_eval = None
+
+        for images, labels in train_loader:
+            optimizer.zero_grad()
+            preds, loss = _step_loss(unet, images, labels, device, True)
+            loss.backward()
+            optimizer.step()
+            total_loss += loss.detach()
+            masks = hip_optim.argmax2(preds.detach())
+            if train_eval is None:                              # Q5: first sample of the epoch only
+                train_eval = evaluation_metrics(masks[0].detach(), labels[0, 0, :, :].detach())
+        train_eval_epoch = np.mean(train_eval, axis=1)
+
+        with torch.no_grad():
+            for images, labels in val_loader:
+                preds, loss = _step_loss(unet, images, labels, device, False)
+                total_loss_val += loss
+                masks = hip_optim.argmax2(preds)
+                if val_eval is None:
+                    val_eval = evaluation_metrics(masks[0].detach(), labels[0, 0, :, :].detach())
+        val_eval_epoch = np.mean(val_eval, axis=1)
+
+        scheduler.step(total_loss_val / (len(val_loader) * batch_size))
+        for param_group in optimizer.param_groups:
+            l_rate = param_group['lr']
+
+        loss_epoch = total_loss / (len(train_loader) * batch_size)
+        loss_epoch_val = total_loss_val / (len(val_loader) * batch_size)
+
+        if loss_epoch_val < (loss_best_epoch * (1.0 - scheduler.threshold)):
+            loss_best_epoch = loss_epoch_val
+            print('New best epoch!')
+            my_patience = 0
+            PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_best.pth')
+            torch.save(unet.state_dict(), PATH)
+            print('Model has been saved:')
+            print(PATH)
+        else:
+            my_patience += 1
+
+        print('Current lr is:             ', l_rate)
+        print('Patience is:                {}/{}'.format(my_patience, scheduler.patience))
+        print('Mean IoU training:         ', "{:.6f}".format(train_eval_epoch[0]))
+        print('Mean PE training:          ', "{:.6f}".format(train_eval_epoch[1]))
+        print('Mean IoU validation:       ', "{:.6f}".format(val_eval_epoch[0]))
+        print('Mean PE validation:        ', "{:.6f}".format(val_eval_epoch[1]))
+        print('Total training loss:       ', "{:.6f}".format(loss_epoch.item()))
+        print('Total validation loss:     ', "{:.6f}".format(loss_epoch_val.item()))
+        print('Best epoch validation loss:', "{:.6f}".format(float(loss_best_epoch)))
+        print('Epoch duration:            ', "{:.6f}".format(time() - start), 's')
+        print(' ')
+
+        # progress series, same six files as the reference (trainer.py:178-183)
+        new = dict(train_iou=train_eval_epoch[0], train_pe=train_eval_epoch[1], val_iou=val_eval_epoch[0],
+                   val_pe=val_eval_epoch[1], loss=loss_epoch.item(), loss_val=loss_epoch_val.item())
+        for k, v in new.items():
+            progress[k] = np.array([v]) if progress[k] is None else np.append(progress[k], [v])
+        pdir = os.path.join(fold_dir, 'progress')
+        np.savetxt(os.path.join(pdir, 'train_eval_iou.out'), progress['train_iou'])
+        np.savetxt(os.path.join(pdir, 'train_eval_pe.out'), progress['train_pe'])
+        np.savetxt(os.path.join(pdir, 'val_eval_iou.out'), progress['val_iou'])
+        np.savetxt(os.path.join(pdir, 'val_eval_pe.out'), progress['val_pe'])
+        np.savetxt(os.path.join(pdir, 'loss.out'), progress['loss'])
+        np.savetxt(os.path.join(pdir, 'loss_val.out'), progress['loss_val'])
+
+        if when_to_stop is not None:
+            if val_eval_epoch[0] > goal:
+                PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_{}.pth'.format(DATASET))
+                torch.save(unet.state_dict(), PATH)
+                print('The goal was reached in epoch {}!'.format(epoch))
+                when_to_stop = None
+            continue
+
+        if epoch % 25 == 0:
+            PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_latest.pth')
+            torch.save(unet.state_dict(), PATH)
+            print('Model has been saved:')
+            print(PATH)
+
+        if l_rate < 10 * scheduler.eps and my_patience == scheduler.patience:
+            print(f'LR dropped below {10 * scheduler.eps}!')
+            print('Stopping training')
+            print(' ')
+            PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_latest.pth')
+            torch.save(unet.state_dict(), PATH)
+            print('Model has been saved:')
+            print(PATH)
+            break
+
+        if my_patience == scheduler.patience:
+            my_patience = -1
+
+    print('Training is finished as epoch {} has been reached'.format(epoch))
+    print(' ')

@@ -1,0 +1,178 @@
+/*
+ * unet_hip.h — C ABI of libunet_hip.so: the MI355X (gfx950) U-Net forward+backward hot path.
+ *
+ * Drop-in boundary for nsirons/DL-unet's `Unet.forward` (+ its autograd backward) and the
+ * step either side of it.  Each entry point names the reference interface it replaces
+ * (file:line in the reference repo).  Plain C: pointers are DEVICE pointers unless stated,
+ * sizes are ints/size_t, `stream` is a hipStream_t passed as void* (0 = default stream).
+ *
+ * Conventions
+ *   - return 0 = ok; <0 = library error (UNET_E_*); >0 = hipError_t.  unet_last_error()
+ *     returns a thread-local message.  No entry point synchronises the host or allocates
+ *     device memory, except unet_create()/unet_destroy() (a 4 KiB zero page per handle).
+ *   - Public tensors keep the reference's layouts: images/logits NCHW fp32, conv weights
+ *     OIHW, transposed-conv weights IOHW, int64 labels/masks.  Internally activations are
+ *     NHWC fp32 (per-op entry points take NHWC).
+ *   - The caller owns every buffer, including the workspace (size: unet_workspace_bytes).
+ *   - All work is enqueued on the caller's stream; a handle is re-entrant per stream.
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_N_PARAMS 46          /* 23 layers x (weight, bias), network.py:23-58 order */
+#define UNET_N_LAYERS 23
+
+enum {
+    UNET_E_BADSIZE  = -1,         /* S must be 16L+60 with L even >= 8 (network.py:124-127, Q7) */
+    UNET_E_BADARG   = -2,
+    UNET_E_NOTREADY = -3,         /* backward without a training forward on this workspace */
+    UNET_E_UNSUPPORTED = -4
+};
+
+typedef struct unet_handle unet_handle;
+
+typedef struct unet_config {
+    int base_ch;                  /* 64 in the reference (network.py:23); 32 for config #5 */
+    int device;                   /* HIP device ordinal */
+} unet_config;
+
+const char *unet_last_error(void);
+int unet_abi_version(void);
+
+/* ---- handle ------------------------------------------------------------------------------
+ * replaces: Unet.__init__ bookkeeping that is not parameters (network.py:20-58).            */
+int unet_create(unet_handle **out, const unet_config *cfg);
+int unet_destroy(unet_handle *h);
+
+/* Size contract of the valid-conv net (functions.py:121-146 input_size_compute):
+ * returns 0 and writes out_size = S-184 when S = 16L+60, L even >= 8; UNET_E_BADSIZE else. */
+int unet_output_size(int S, int *out_size);
+int unet_param_count(const unet_handle *h, int idx, size_t *numel);   /* idx in [0,46) */
+
+/* Bytes of caller-provided workspace for a batch of B tiles of S x S.
+ * training=1 also reserves gradient/activation-gradient storage for unet_backward.        */
+size_t unet_workspace_bytes(const unet_handle *h, int B, int S, int training);
+
+/* ---- whole path ---------------------------------------------------------------------------
+ * replaces: Unet.forward (network.py:129-192), called at trainer.py:58,100 and tester.py:27.
+ *   params : host array of 46 device pointers, reference state-dict order/layout (fp32)
+ *   x      : [B,1,S,S] fp32;  logits : [B,2,S-184,S-184] fp32 NCHW
+ *   training=1 keeps the activation stash in `workspace` for unet_backward.               */
+int unet_forward(unet_handle *h, const void *const *params, const void *x, void *logits,
+                 int B, int S, void *workspace, size_t workspace_bytes, int training,
+                 void *stream);
+
+/* replaces: the autograd backward of every op in Unet.forward, triggered by
+ * loss.backward() at trainer.py:77.
+ *   dlogits : [B,2,So,So] fp32 NCHW (contiguous)
+ *   grads   : host array of 46 device pointers, same shapes/layouts as params; OVERWRITTEN
+ * Stages let the caller overlap the gradient all-reduce with the rest of the backward:
+ * stage s in [0, unet_backward_stages()) must be run in increasing order; after stage s
+ * returns, every gradient tensor listed by unet_backward_stage_params(s) is final (in
+ * stream order).  unet_backward == all stages.                                              */
+int unet_backward(unet_handle *h, const void *const *params, const void *dlogits,
+                  void *const *grads, void *workspace, size_t workspace_bytes, void *stream);
+int unet_backward_stages(void);
+int unet_backward_stage(unet_handle *h, int stage, const void *const *params,
+                        const void *dlogits, void *const *grads, void *workspace,
+                        size_t workspace_bytes, void *stream);
+/* writes up to cap parameter indices completed by `stage`; returns how many */
+int unet_backward_stage_params(int stage, int *idx, int cap);
+
+/* Algorithmic FLOPs (2*MAC) of one forward / forward+backward for B tiles of S. */
+double unet_flops(const unet_handle *h, int B, int S, int backward);
+
+/* ---- measurement -----------------------------------------------------------------------------
+ * Optional HIP-event timing around every launch of a kernel family, recorded on the launch
+ * stream (bench.py's roofline.achieved is measured with this inside its timed region).
+ * family: 0 = implicit-GEMM (conv fwd / dgrad / up-conv), 1 = weight-gradient, 2 = its reduce.
+ * unet_profile_read synchronises on the recorded events and returns totals since the last reset:
+ * elapsed ms, launch count and the algorithmic FLOPs (2*MAC, in-bounds taps only) of the launches. */
+int unet_profile_enable(int on);
+int unet_profile_reset(void);
+int unet_profile_read(int family, double *ms_total, long *launches, double *flops_total);
+
+/* ---- step-side kernels (L1-L3) -------------------------------------------------------------
+ * L1 replaces nn.BCEWithLogitsLoss(weight=w)(preds, ll) + its backward (trainer.py:63-77).
+ *   logits/target/dlogits : [B,2,H,W] fp32 contiguous; target is the one-hot `ll`
+ *   weight : NULL, or fp32 with element strides (wsB,wsC,wsH,wsW) (0 = broadcast dim) —
+ *            the caller decides the broadcast (reference: Q4 aligns B with the class axis)
+ *   loss_out : 1 fp32 (mean over B*2*H*W); dlogits may be NULL; grad_scale multiplies the
+ *            gradient (1/world_size for data parallel).  scratch: >= unet_bce_scratch_bytes */
+size_t unet_bce_scratch_bytes(size_t numel);
+int unet_bce_logits(const void *logits, const void *target, const void *weight,
+                    long wsB, long wsC, long wsH, long wsW, int B, int H, int W,
+                    void *loss_out, void *dlogits, float grad_scale, void *scratch, void *stream);
+/* builds ll from integer labels on device: ll[:,0]=1-y, ll[:,1]=y (trainer.py:63-66) */
+int unet_onehot2(const void *labels_i64, void *target, int B, int H, int W, void *stream);
+
+/* L2 replaces preds.argmax(dim=1) (trainer.py:82, tester.py:30): [B,2,H,W] fp32 with row
+ * stride ld (elements) and plane stride ps -> [B,H,W] int64; ties -> class 0.               */
+int unet_argmax2(const void *logits, long batch_stride, long plane_stride, long row_stride,
+                 void *out_i64, int B, int H, int W, void *stream);
+
+/* L3 replaces optim.SGD(lr, momentum).step() (trainer.py:30,78): for each of n tensors
+ * buf = first ? g : mu*buf + g ; p -= lr*buf.  Pointer tables are HOST arrays.             */
+int unet_sgd_momentum(void *const *params, const void *const *grads, void *const *bufs,
+                      const size_t *numel, int n, float lr, float mu, int first_step,
+                      void *stream);
+
+/* ---- per-op entry points (NHWC fp32), used by the unit tests ---------------------------------
+ * Each replaces the ATen op dispatched at the cited line.  w_* are in reference layout.    */
+/* nn.Conv2d(3x3, valid)+ReLU, network.py:131-188.  Second source (x2) is the virtual
+ * crop_and_concat (network.py:108-127): x1 = skip [B,H1,W1,C1] zero-padded by pad1 per side,
+ * x2 = up-conv output [B,H,W,C2]; pass x2=NULL,C2=0,pad1=0 for a plain conv.  H,W = extent of
+ * the (virtual) input; y : [B,H-2,W-2,K].  scratch >= unet_conv3x3_scratch_bytes(C1+C2,K).  */
+size_t unet_conv3x3_scratch_bytes(int C, int K);
+int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2,
+                     int B, int H, int W, const void *w_oihw, const void *bias, int K, int relu,
+                     void *y, void *scratch, void *stream);
+/* backward of the same: dz is the gradient w.r.t. the PRE-activation of this conv
+ * ([B,H-2,W-2,K]).  Outputs (any may be NULL): dx1 [B,H1,W1,C1] (crop of the padded region),
+ * dx2 [B,H,W,C2], dw OIHW, db.  mask1/mask2: if non-NULL, dx is multiplied by (mask>0)
+ * (ReLU backward of the producer).  add1: if non-NULL it is added to dx1 (skip gradient).
+ * scratch >= unet_conv3x3_bwd_scratch_bytes(B,H,W,C1+C2,K).                                  */
+size_t unet_conv3x3_bwd_scratch_bytes(int B, int H, int W, int C, int K);
+int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2,
+                     int B, int H, int W, const void *w_oihw, int K, const void *dz,
+                     void *dx1, const void *mask1, const void *add1, void *dx2, const void *mask2,
+                     void *dw, void *db, void *scratch, void *stream);
+/* F.max_pool2d(2,2), network.py:133-151 and its backward fused with the ReLU backward of
+ * the pooled tensor's producer: dpre = route(dy) * (pre > 0).                              */
+int unet_maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, void *stream);
+int unet_maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C,
+                      void *stream);
+/* nn.ConvTranspose2d(k2,s2), network.py:159-183: x [B,H,W,Ci] -> y [B,2H,2W,Co]; w IOHW. */
+size_t unet_upconv2_scratch_bytes(int B, int H, int W, int Ci, int Co);
+int unet_upconv2_fwd(const void *x, int B, int H, int W, int Ci, const void *w_iohw,
+                     const void *bias, int Co, void *y, void *scratch, void *stream);
+int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_iohw, int Co,
+                     const void *dy, void *dx, const void *mask, void *dw, void *db,
+                     void *scratch, void *stream);
+/* finalconv 1x1 (network.py:190): x NHWC [B,H,W,C] -> logits NCHW [B,2,H,W]; and backward:
+ * dz = (dlogits . W) * (x > 0) (x is the ReLU output of conv12e), dw [2,C,1,1], db [2].     */
+int unet_head1x1_fwd(const void *x, int B, int H, int W, int C, const void *w, const void *bias,
+                     void *logits, void *stream);
+size_t unet_head1x1_bwd_scratch_bytes(int B, int H, int W, int C);
+int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w,
+                     const void *dlogits, void *dz, void *dw, void *db, void *scratch,
+                     void *stream);
+/* conv11c (network.py:23,131): the 1->K stencil layer, direct HBM-bound kernel.
+ * x [B,S,S] -> y [B,S-2,S-2,K] (+ReLU); backward gives dw [K,1,3,3], db [K] only.          */
+int unet_conv1ch_fwd(const void *x, int B, int S, const void *w, const void *bias, int K,
+                     void *y, void *stream);
+size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K);
+int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *dw, void *db,
+                     void *scratch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H */

@@ -1,0 +1,208 @@
+"""Whole-path parity of the HIP U-Net (through network.Unet -> C ABI) against the golden vectors
+captured from the imported reference, the C oracle and the torch restatement.
+
+Tolerances (north_star "within 1e-3 rel fp32"): errors are normalised by tensor scale,
+|d|_inf/|ref|_inf, and judged against the fp64 run of the reference: forward <= 2e-5 (the reference's
+own fp32 run sits at ~1e-6), gradients <= 1e-3 per tensor.  argmax masks: bit-exact on every pixel
+whose fp64 margin exceeds the recorded threshold."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-5
+GRAD_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def net():
+    import network
+    from oracle import prng
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    m = network.Unet()
+    sd = {k: torch.from_numpy(v) for k, v in prng.make_params(0).items()}
+    m.load_state_dict(sd)
+    return m.to("cuda:0")
+
+
+def nerr(a, ref):
+    a = np.asarray(a, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def run(net, S, B, with_grad, seed_x=1):
+    from oracle import prng
+    x = torch.from_numpy(prng.make_input(seed_x, B, S)).cuda()
+    net.zero_grad(set_to_none=True)
+    if not with_grad:
+        with torch.no_grad():
+            return net(x).cpu().numpy(), None
+    y = net(x)
+    dl = torch.from_numpy(prng.make_cotangent(2, (B, 2, S - 184, S - 184))).cuda()
+    y.backward(dl)
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+    return y.detach().cpu().numpy(), grads
+
+
+@pytest.mark.parametrize("S", [188, 220])
+def test_forward_backward_vs_reference_golden(net, golden_dir, S):
+    g = np.load(os.path.join(golden_dir, "unet_S%d.npz" % S))
+    logits, grads = run(net, S, 2, True)
+    assert nerr(logits, g["logits_f64"]) < FWD_TOL
+    names = [str(n) for n in g["names"]]
+    sums, samp, idx = g["grad_sums_f64"], g["grad_samp_f64"], g["grad_samp_idx"]
+    for i, k in enumerate(names):
+        a = grads[k].astype(np.float64).ravel()
+        l2 = np.sqrt((a * a).sum())
+        assert abs(l2 - sums[i, 1]) <= GRAD_TOL * sums[i, 1], (k, l2, sums[i, 1])
+        assert np.abs(a[idx[i]] - samp[i]).max() <= GRAD_TOL * sums[i, 2], k
+    for k in ("conv11c.weight", "conv11c.bias", "finalconv.weight", "finalconv.bias", "conv52c.bias", "upconv4.bias"):
+        assert nerr(grads[k], g["grad_full_%s_f64" % k]) < GRAD_TOL, k
+    # inference path (no stash) gives the same logits bit for bit
+    logits_ng, _ = run(net, S, 2, False)
+    assert np.array_equal(logits_ng, logits)
+
+
+def test_every_gradient_element_vs_c_oracle_f64(net):
+    """All 31,030,658 gradient elements at S=188 against the fp64 C oracle (not just samples)."""
+    from oracle import oracle_c, prng
+    S, B = 188, 2
+    logits, grads = run(net, S, B, True)
+    p64 = {k: v.astype(np.float64) for k, v in prng.make_params(0).items()}
+    ref_logits, ref_grads = oracle_c.unet_fwd_bwd(p64, prng.make_input(1, B, S).astype(np.float64),
+                                                  dlogits=prng.make_cotangent(2, (B, 2, 4, 4)).astype(np.float64))
+    assert nerr(logits, ref_logits) < FWD_TOL
+    worst = max(nerr(grads[k], ref_grads[k]) for k in grads)
+    assert worst < GRAD_TOL, worst
+
+
+def test_S572_forward_and_bit_exact_argmax(net, golden_dir):
+    import optim as hip_optim
+    g = np.load(os.path.join(golden_dir, "unet_S572_fwd.npz"))
+    from oracle import prng
+    x = torch.from_numpy(prng.make_input(1, 1, 572)).cuda()
+    with torch.no_grad():
+        y = net(x)
+    assert nerr(y.cpu().numpy()[:, :, ::6, ::6], g["logits_sample_f64"]) < FWD_TOL
+    am = hip_optim.argmax2(y).cpu().numpy().ravel()
+    ref = np.unpackbits(g["argmax_packed"])[: am.size]
+    safe = np.ones(am.size, bool); safe[g["low_margin_idx"]] = False
+    assert (am[safe] == ref[safe]).all()
+    assert (am != ref).sum() <= g["low_margin_idx"].size
+
+
+def test_S572_batch8_properties(net):
+    """BASELINE config #2 size (B=8, 572): batch independence (bit-exact: the K order of every output
+    element does not depend on the tiling of M) and additivity of gradients over the batch."""
+    from oracle import prng
+    S, B = 572, 8
+    x = torch.from_numpy(prng.make_input(5, B, S)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(6, (B, 2, 388, 388))).cuda()
+    net.zero_grad(set_to_none=True)
+    y = net(x)
+    y.backward(dl)
+    g_all = [p.grad.clone() for p in net.parameters()]
+    with torch.no_grad():
+        y0 = net(x[0:1].contiguous()); y7 = net(x[7:8].contiguous())
+    assert torch.equal(y0[0], y[0]) and torch.equal(y7[0], y[7])
+    acc = None
+    for lo, hi in ((0, 3), (3, 8)):                 # ragged split
+        net.zero_grad(set_to_none=True)
+        net(x[lo:hi].contiguous()).backward(dl[lo:hi].contiguous())
+        part = [p.grad.clone() for p in net.parameters()]
+        acc = part if acc is None else [a + b for a, b in zip(acc, part)]
+    for a, b in zip(acc, g_all):
+        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < 1e-4
+
+
+def test_full_size_vs_torch_restatement(net):
+    """Full-size (S=572) forward + backward against the torch restatement run on the host CPU in fp32."""
+    from oracle import prng, torch_ref
+    S, B = 572, 1
+    logits, grads = run(net, S, B, True)
+    p = torch_ref.params_to_torch(prng.make_params(0), torch.float32, requires_grad=True)
+    x = torch.from_numpy(prng.make_input(1, B, S))
+    y = torch_ref.unet_forward(p, x)
+    y.backward(torch.from_numpy(prng.make_cotangent(2, (B, 2, 388, 388))))
+    assert nerr(logits, y.detach().numpy()) < FWD_TOL
+    for k in grads:
+        assert nerr(grads[k], p[k].grad.numpy()) < GRAD_TOL, k
+
+
+def test_bad_sizes_raise_like_the_reference(net):
+    # odd size difference in crop_and_concat -> torch.cat raises in the reference (Q7)
+    for S in (570, 200, 187, 60):
+        with pytest.raises(RuntimeError):
+            net(torch.zeros(1, 1, S, S, device="cuda"))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 2, 188, 188, device="cuda"))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 188, 188))            # host tensor: no CPU fallback
+
+
+def test_odd_batch_and_state_dict_roundtrip(net, tmp_path):
+    import network
+    from oracle import prng
+    x = torch.from_numpy(prng.make_input(9, 3, 188)).cuda()
+    with torch.no_grad():
+        y3 = net(x)
+    path = os.path.join(tmp_path, "w.pth")
+    torch.save(net.state_dict(), path)
+    m2 = network.Unet()
+    m2.load_state_dict(torch.load(path, weights_only=True))
+    m2 = m2.to("cuda:0")
+    with torch.no_grad():
+        assert torch.equal(m2(x), y3)
+
+
+def test_training_and_testing_loops(net, tmp_path, capsys):
+    """trainer.training / tester.testing keep the reference's call surface and artefacts
+    (progress/*.out, models/*.pth, images|labels|preds/*.tif, test_iou.out, test_pe.out)."""
+    import copy
+    from oracle import prng
+    from trainer import training
+    from tester import testing
+    m = copy.deepcopy(net)
+    S, So = 188, 4
+
+    def loader(seed, n):
+        out = []
+        for i in range(n):
+            out.append((torch.from_numpy(prng.make_input(seed + i, 2, S)), torch.from_numpy(prng.make_labels(seed + i, 2, So))))
+        return out
+
+    before = [p.detach().clone() for p in m.parameters()]
+    training(m, loader(10, 2), loader(20, 1), 1, 2, torch.device("cuda:0"), str(tmp_path), "ISBI2012")
+    for f in ("train_eval_iou", "train_eval_pe", "val_eval_iou", "val_eval_pe", "loss", "loss_val"):
+        assert np.loadtxt(os.path.join(tmp_path, "progress", f + ".out")).size == 2
+    assert os.path.exists(os.path.join(tmp_path, "models", "unet_weight_save_best.pth"))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+    tl = [(torch.from_numpy(prng.make_input(30, 1, S)), torch.from_numpy(prng.make_labels(30, 1, So)))]
+    out = os.path.join(tmp_path, "test_out")
+    testing(m, tl, 1, torch.device("cuda:0"), out)
+    for sub, f in (("images", "image0.tif"), ("labels", "label0.tif"), ("preds", "pred0.tif")):
+        assert os.path.exists(os.path.join(out, sub, f))
+    assert np.loadtxt(os.path.join(out, "test_iou.out")).shape == (2,)
+
+
+def test_trainer_loss_matches_reference_bce(net, golden_dir):
+    """The trainer's loss on golden logits reproduces the reference's weighted BCE (Q4 broadcast)."""
+    import optim as hip_optim
+    from oracle import prng
+    ka = np.load(os.path.join(golden_dir, "known_answers.npz"))
+    g = np.load(os.path.join(golden_dir, "unet_S220.npz"))
+    lg = torch.from_numpy(g["logits_f64"]).float().cuda().requires_grad_(True)
+    labels = torch.from_numpy(prng.make_labels(3, 2, 36))
+    ll = hip_optim.onehot2(labels, lg)
+    wm = torch.from_numpy(ka["class_balance_rand"]).float().cuda()
+    loss = hip_optim.bce_with_logits(lg, ll, weight=wm)
+    loss.backward()
+    assert abs(loss.item() - float(ka["bce_weighted_loss"])) < 1e-5 * float(ka["bce_weighted_loss"])
+    assert nerr(lg.grad.cpu().numpy(), ka["bce_weighted_grad"]) < 1e-5
+    with pytest.raises(RuntimeError):                # Q4: B=3 cannot broadcast, like the reference
+        hip_optim.bce_with_logits(torch.zeros(3, 2, 4, 4, device="cuda"), torch.zeros(3, 2, 4, 4, device="cuda"),
+                                  weight=torch.ones(3, 4, 4, device="cuda"))
