@@ -30,6 +30,7 @@ _SIGS = {
     "unet_backward_stage": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]),
     "unet_backward_stage_params": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
     "unet_flops": (C.c_double, [vp, C.c_int, C.c_int, C.c_int]),
+    "unet_debug_buffer": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "unet_profile_enable": (C.c_int, [C.c_int]),
     "unet_profile_reset": (C.c_int, []),
     "unet_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
@@ -145,6 +146,14 @@ class Handle:
         if n == 0:
             check(-1, "unet_workspace_bytes")
         return n
+
+    def buffer_view(self, ws, B, S, training, name):
+        """NHWC [B,e,e,C] float32 view of a named plan buffer inside workspace tensor `ws` (debug/tests)."""
+        off, e, c = C.c_size_t(), C.c_int(), C.c_int()
+        check(lib().unet_debug_buffer(self._h, B, S, int(training), name.encode(), C.byref(off), C.byref(e), C.byref(c)),
+              "unet_debug_buffer")
+        n = B * e.value * e.value * c.value
+        return ws[off.value:off.value + 4 * n].view(torch.float32).view(B, e.value, e.value, c.value)
 
     def flops(self, B, S, backward):
         return lib().unet_flops(self._h, B, S, int(backward))

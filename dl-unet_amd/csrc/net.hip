@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <utility>
@@ -206,7 +207,9 @@ static int make_plan(Plan &pl, int base, int B, int S, int training)
     int d = pl.ea2[4];
     for (int l = 3; l >= 0; --l) {
         pl.eu[l] = 2 * d; pl.pad[l] = (pl.eu[l] - pl.et[l]) / 2;
-        if (pl.pad[l] < 0 || (pl.eu[l] - pl.et[l]) % 2) { set_error("internal: skip geometry"); return UNET_E_BADSIZE; }
+        // pad > 0: the skip is zero-padded (every S >= 380); pad < 0: it is cropped (188 <= S < 380).
+        // Both are the reference's F.pad(A, (-c,)*4) with c = int((A-B)/2) (network.py:124-126).
+        if ((pl.eu[l] - pl.et[l]) % 2) { set_error("internal: odd skip difference"); return UNET_E_BADSIZE; }
         pl.ed1[l] = pl.eu[l] - 2; pl.ed2[l] = pl.eu[l] - 4; d = pl.ed2[l];
     }
     pl.So = d;
@@ -394,6 +397,40 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
     if ((rc = unet_head1x1_fwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), PARAM(2 * FINAL + 1), logits, stream))) return rc;
     if (training) h->remember(workspace, pl);
     return 0;
+}
+
+/* Debug/introspection: byte offset and element count of a named workspace buffer, e.g. "a1_0",
+ * "a2_4", "t_2", "u_3", "d1_0", "d2_3", and with training=1 "g_a1_0", "g_a2_4", "g_t_1", "g_ts_1",
+ * "g_u_2", "g_d1_3", "g_d2_3", "xin".  Tensors are NHWC [B,e,e,C]; *extent/*channels describe them. */
+int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const char *name,
+                      size_t *offset, int *extent, int *channels)
+{
+    ARG_CHECK(h && name && offset && extent && channels, "unet_debug_buffer: null argument");
+    Plan pl;
+    int rc = make_plan(pl, h->base_ch, B, S, training);
+    if (rc) return rc;
+    char kind[16];
+    int l = 0;
+    const char *us = strrchr(name, '_');
+    if (!strcmp(name, "xin")) { ARG_CHECK(training, "xin exists only with training=1"); *offset = pl.xin; *extent = S; *channels = 1; return 0; }
+    ARG_CHECK(us && (size_t)(us - name) < sizeof(kind), "unet_debug_buffer: bad name %s", name);
+    memcpy(kind, name, us - name); kind[us - name] = 0;
+    l = atoi(us + 1);
+    ARG_CHECK(l >= 0 && l < 5, "unet_debug_buffer: bad level in %s", name);
+    const bool g = !strncmp(kind, "g_", 2);
+    ARG_CHECK(!g || training, "gradient buffers exist only with training=1");
+    const char *k = g ? kind + 2 : kind;
+    *channels = pl.ch[l];
+    if (!strcmp(k, "a1")) { *offset = g ? pl.g_a1[l] : pl.a1[l]; *extent = pl.ea1[l]; return 0; }
+    if (!strcmp(k, "a2")) { *offset = g ? pl.g_a2[l] : pl.a2[l]; *extent = pl.ea2[l]; return 0; }
+    ARG_CHECK(l < 4, "unet_debug_buffer: bad level in %s", name);
+    if (!strcmp(k, "t")) { *offset = g ? pl.g_t[l] : pl.t[l]; *extent = pl.et[l]; return 0; }
+    if (!strcmp(k, "ts") && g) { *offset = pl.g_ts[l]; *extent = pl.et[l]; return 0; }
+    if (!strcmp(k, "u")) { *offset = g ? pl.g_u[l] : pl.u[l]; *extent = pl.eu[l]; return 0; }
+    if (!strcmp(k, "d1")) { *offset = g ? pl.g_d1[l] : pl.d1[l]; *extent = pl.ed1[l]; return 0; }
+    if (!strcmp(k, "d2")) { *offset = g ? pl.g_d2[l] : pl.d2[l]; *extent = pl.ed2[l]; return 0; }
+    set_error("unet_debug_buffer: unknown buffer %s", name);
+    return UNET_E_BADARG;
 }
 
 // ---- backward ------------------------------------------------------------------------------------

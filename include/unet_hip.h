@@ -89,6 +89,12 @@ int unet_backward_stage_params(int stage, int *idx, int cap);
 /* Algorithmic FLOPs (2*MAC) of one forward / forward+backward for B tiles of S. */
 double unet_flops(const unet_handle *h, int B, int S, int backward);
 
+/* Debug/introspection: byte offset into the workspace, extent e and channel count of a named NHWC
+ * [B,e,e,C] buffer of the plan for (B,S,training): activations "a1_l","a2_l" (l=0..4), "t_l","u_l",
+ * "d1_l","d2_l" (l=0..3); with training=1 also their gradients "g_*", "g_ts_l" and "xin". */
+int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const char *name,
+                      size_t *offset, int *extent, int *channels);
+
 /* ---- measurement -----------------------------------------------------------------------------
  * Optional HIP-event timing around every launch of a kernel family, recorded on the launch
  * stream (bench.py's roofline.achieved is measured with this inside its timed region).

@@ -33,8 +33,11 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def unet_fwd_bwd(params, x, base=64, dlogits=None):
-    """params: ordered dict of 46 arrays; x [N,1,S,S]. Returns (logits, grads|None)."""
+def unet_fwd_bwd(params, x, base=64, dlogits=None, relu_masks=None, pool_sel=None):
+    """params: ordered dict of 46 arrays; x [N,1,S,S]. Returns (logits, grads|None).
+    relu_masks (18 uint8 NCHW arrays: a1_l,a2_l at 2l,2l+1; d1_l,d2_l at 10+2l,11+2l) and pool_sel
+    (4 uint8 NCHW arrays, winner 0..3) evaluate the net on the SAME piecewise-linear branch as
+    another run (see unet_oracle_body.h)."""
     dt = x.dtype
     names = list(params.keys())
     arrs = [np.ascontiguousarray(params[k], dtype=dt) for k in names]
@@ -48,8 +51,15 @@ def unet_fwd_bwd(params, x, base=64, dlogits=None):
         grads = [np.empty_like(a) for a in arrs]
         gp = PT(*[g.ctypes.data for g in grads])
         dlogits = np.ascontiguousarray(dlogits, dtype=dt)
+    mp = sp = None
+    if relu_masks is not None:
+        relu_masks = [np.ascontiguousarray(m, dtype=np.uint8) for m in relu_masks]
+        pool_sel = [np.ascontiguousarray(m, dtype=np.uint8) for m in pool_sel]
+        assert len(relu_masks) == 18 and len(pool_sel) == 4
+        mp = (C.c_void_p * 18)(*[m.ctypes.data for m in relu_masks])
+        sp = (C.c_void_p * 4)(*[m.ctypes.data for m in pool_sel])
     fn = getattr(lib(), "oracle_unet_fwd_bwd" + _sfx(dt))
-    rc = fn(pp, _p(np.ascontiguousarray(x)), N, S, base, _p(logits), _p(dlogits), gp)
+    rc = fn(pp, _p(np.ascontiguousarray(x)), N, S, base, _p(logits), _p(dlogits), gp, mp, sp)
     if rc != 0:
         raise RuntimeError("oracle: size rejected (reference would raise), rc=%d" % rc)
     return logits, (dict(zip(names, grads)) if grads is not None else None)

@@ -1,0 +1,80 @@
+"""TEST INFRASTRUCTURE — drives the HIP path through the C ABI and checks it against the fp64 C oracle
+evaluated on the SAME piecewise-linear branch (same ReLU masks and max-pool winners).
+
+Why "same branch": a ReLU whose pre-activation is within fp32 noise of zero, or a pool window with a
+near-tie, lands on a different linear piece in two correct fp32 evaluations (and in fp64); the
+gradient of that element then differs by O(1) and, through the small deep feature maps, moves whole
+weight-gradient tensors by ~1e-2 (measured: at S=220 a single flipped element of conv42e's output
+changes every upstream gradient by 0.5-1%; the plain-C fp32 oracle shows the same 4e-3..2e-2 at
+S=572).  The reference's own fp32 CPU run has the same property.  On the same branch the
+function is linear in every ReLU/pool and parity is tight.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import oracle_c, prng
+
+RELU_BUFS = ["a1_0", "a2_0", "a1_1", "a2_1", "a1_2", "a2_2", "a1_3", "a2_3", "a1_4", "a2_4",
+             "d1_0", "d2_0", "d1_1", "d2_1", "d1_2", "d2_2", "d1_3", "d2_3"]
+
+
+def nerr(a, ref):
+    a = np.asarray(a, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+def hip_forward_backward(params, x, dlogits, device=0):
+    """Runs unet_forward(training) + unet_backward through the C ABI on caller-owned buffers.
+    Returns (logits, grads dict, handle, workspace, keepalive)."""
+    import _hip
+    import network
+    L = _hip.lib()
+    dev = torch.device("cuda", device)
+    names = list(params.keys())
+    B, _, S, _ = x.shape
+    h = network._handle(device)
+    plist = [torch.from_numpy(np.ascontiguousarray(params[k])).to(dev) for k in names]
+    nbytes = h.workspace_bytes(B, S, True)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    xd = torch.from_numpy(x).to(dev)
+    logits = torch.empty(B, 2, S - 184, S - 184, device=dev)
+    ptab = _hip.ptr_table(plist)
+    _hip.check(L.unet_forward(h.h, ptab, _hip.ptr(xd), _hip.ptr(logits), B, S, _hip.ptr(ws), nbytes, 1, _hip.stream()), "unet_forward")
+    grads = [torch.empty_like(p) for p in plist]
+    gtab = _hip.ptr_table(grads)
+    dld = torch.from_numpy(np.ascontiguousarray(dlogits)).to(dev)
+    _hip.check(L.unet_backward(h.h, ptab, _hip.ptr(dld), gtab, _hip.ptr(ws), nbytes, _hip.stream()), "unet_backward")
+    torch.cuda.synchronize()
+    return logits.cpu().numpy(), {k: g.cpu().numpy() for k, g in zip(names, grads)}, h, ws
+
+
+def branch_of(h, ws, B, S):
+    """ReLU masks (18) and pool winners (4) of the HIP forward, NCHW uint8."""
+    masks = []
+    for name in RELU_BUFS:
+        v = h.buffer_view(ws, B, S, True, name)
+        masks.append((v > 0).permute(0, 3, 1, 2).contiguous().to(torch.uint8).cpu().numpy())
+    sels = []
+    for l in range(4):
+        v = h.buffer_view(ws, B, S, True, "a2_%d" % l)                      # [B,H,W,C]
+        Bq, H, W, Cc = v.shape
+        win = v.view(Bq, H // 2, 2, W // 2, 2, Cc).permute(0, 5, 1, 3, 2, 4).reshape(Bq, Cc, H // 2, W // 2, 4)
+        sels.append(win.argmax(dim=-1).to(torch.uint8).cpu().numpy())       # first maximum on ties
+    return masks, sels
+
+
+def check_same_branch(S, B, seed_w=0, seed_x=1, seed_dl=2, dlogits=None):
+    """Returns dict(fwd=..., grads={name: err}) of the HIP path against the fp64 oracle on HIP's branch."""
+    params = prng.make_params(seed_w)
+    x = prng.make_input(seed_x, B, S)
+    dl = dlogits if dlogits is not None else prng.make_cotangent(seed_dl, (B, 2, S - 184, S - 184))
+    logits, grads, h, ws = hip_forward_backward(params, x, dl)
+    masks, sels = branch_of(h, ws, B, S)
+    del ws
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref_logits, ref_grads = oracle_c.unet_fwd_bwd(p64, x.astype(np.float64), dlogits=np.asarray(dl, dtype=np.float64),
+                                                  relu_masks=masks, pool_sel=sels)
+    return {"fwd": nerr(logits, ref_logits), "grads": {k: nerr(grads[k], ref_grads[k]) for k in grads},
+            "logits": logits, "hip_grads": grads}

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <stddef.h>
+#include <string.h>
 
 #define REAL float
 #define SUFFIX _f32

@@ -355,6 +355,29 @@ void FN(oracle_sgd_momentum)(REAL *p, const REAL *g, REAL *buf, size_t n,
     }
 }
 
+/* "Same branch" evaluation: ReLU masks / pool selections taken from ANOTHER run (the HIP path's
+ * forward) instead of this run's own signs.  A ReLU or max-pool is piecewise linear; two fp32/fp64
+ * evaluations that take a different piece at a near-zero activation or a near-tie differ by O(1) in
+ * that element's gradient, so gradient parity is asserted on the SAME piece.        */
+void FN(oracle_apply_mask)(REAL *y, const unsigned char *mask, size_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) y[i] = mask[i] ? y[i] : (REAL)0;
+}
+
+void FN(oracle_maxpool2_select)(const REAL *x, REAL *y, const unsigned char *idx, int N, int C, int H, int W)
+{
+    const int Ho = H / 2, Wo = W / 2;
+#pragma omp parallel for schedule(static)
+    for (int nc = 0; nc < N * C; ++nc)
+        for (int oy = 0; oy < Ho; ++oy)
+            for (int ox = 0; ox < Wo; ++ox) {
+                const int mi = idx[((size_t)nc * Ho + oy) * Wo + ox];
+                y[((size_t)nc * Ho + oy) * Wo + ox] =
+                    x[(size_t)nc * H * W + (size_t)(2 * oy + (mi >> 1)) * W + 2 * ox + (mi & 1)];
+            }
+}
+
 /* ------------------------------------------------------------------------------
  * Whole net: Unet.forward (network.py:129-192) and its autograd backward (A23).
  * params: the 46 state-dict tensors in declaration order (network.py:23-58),
@@ -371,8 +394,12 @@ enum { L_C11C, L_C12C, L_C21C, L_C22C, L_C31C, L_C32C, L_C41C, L_C42C, L_C51C, L
 
 int FN(oracle_unet_fwd_bwd)(const REAL *const *params, const REAL *x, int N, int S,
                             int base, REAL *logits, const REAL *dlogits,
-                            REAL *const *grads)
+                            REAL *const *grads,
+                            const unsigned char *const *relu_mask,   /* NULL, or 18 NCHW masks: a1[l],a2[l] at 2l,2l+1; d1[l],d2[l] at 10+2l,11+2l */
+                            const unsigned char *const *pool_sel)    /* NULL, or 4 NCHW selections (0..3) for pool l */
 {
+#define MASKED(buf, idx, n) do { if (relu_mask) FN(oracle_apply_mask)((buf), relu_mask[(idx)], (n)); } while (0)
+#define RELU_BWD(act, g, idx, n) do { if (relu_mask) FN(oracle_apply_mask)((g), relu_mask[(idx)], (n)); else FN(oracle_relu_bwd)((act), (g), (n)); } while (0)
 #define PW(l) params[2 * (l)]
 #define PB(l) params[2 * (l) + 1]
 #define GW(l) (grads ? grads[2 * (l)] : 0)
@@ -392,14 +419,20 @@ int FN(oracle_unet_fwd_bwd)(const REAL *const *params, const REAL *x, int N, int
         if (e_a2[l] <= 0) return -1;
         a1[l] = ALLOC((size_t)N * ch[l] * e_a1[l] * e_a1[l]);
         a2[l] = ALLOC((size_t)N * ch[l] * e_a2[l] * e_a2[l]);
-        FN(oracle_conv_valid_fwd)(src, PW(2 * l), PB(2 * l), a1[l], N, cin, cur, cur, ch[l], 3, 1);
-        FN(oracle_conv_valid_fwd)(a1[l], PW(2 * l + 1), PB(2 * l + 1), a2[l], N, ch[l], e_a1[l], e_a1[l], ch[l], 3, 1);
+        FN(oracle_conv_valid_fwd)(src, PW(2 * l), PB(2 * l), a1[l], N, cin, cur, cur, ch[l], 3, !relu_mask);
+        MASKED(a1[l], 2 * l, (size_t)N * ch[l] * e_a1[l] * e_a1[l]);
+        FN(oracle_conv_valid_fwd)(a1[l], PW(2 * l + 1), PB(2 * l + 1), a2[l], N, ch[l], e_a1[l], e_a1[l], ch[l], 3, !relu_mask);
+        MASKED(a2[l], 2 * l + 1, (size_t)N * ch[l] * e_a2[l] * e_a2[l]);
         if (l < 4) {
             if (e_a2[l] & 1) return -1;
             e_t[l] = e_a2[l] / 2;
             t[l] = ALLOC((size_t)N * ch[l] * e_t[l] * e_t[l]);
             pidx[l] = (unsigned char *)malloc((size_t)N * ch[l] * e_t[l] * e_t[l]);
-            FN(oracle_maxpool2_fwd)(a2[l], t[l], pidx[l], N, ch[l], e_a2[l], e_a2[l]);
+            if (pool_sel) {
+                memcpy(pidx[l], pool_sel[l], (size_t)N * ch[l] * e_t[l] * e_t[l]);
+                FN(oracle_maxpool2_select)(a2[l], t[l], pidx[l], N, ch[l], e_a2[l], e_a2[l]);
+            } else
+                FN(oracle_maxpool2_fwd)(a2[l], t[l], pidx[l], N, ch[l], e_a2[l], e_a2[l]);
             src = t[l]; cur = e_t[l]; cin = ch[l];
         }
     }
@@ -421,8 +454,10 @@ int FN(oracle_unet_fwd_bwd)(const REAL *const *params, const REAL *x, int N, int
         e_d1[l] = e_u[l] - 2; e_d2[l] = e_u[l] - 4;
         d1[l] = ALLOC((size_t)N * ch[l] * e_d1[l] * e_d1[l]);
         d2[l] = ALLOC((size_t)N * ch[l] * e_d2[l] * e_d2[l]);
-        FN(oracle_conv_valid_fwd)(cat[l], PW(c1e_l[l]), PB(c1e_l[l]), d1[l], N, 2 * ch[l], e_u[l], e_u[l], ch[l], 3, 1);
-        FN(oracle_conv_valid_fwd)(d1[l], PW(c2e_l[l]), PB(c2e_l[l]), d2[l], N, ch[l], e_d1[l], e_d1[l], ch[l], 3, 1);
+        FN(oracle_conv_valid_fwd)(cat[l], PW(c1e_l[l]), PB(c1e_l[l]), d1[l], N, 2 * ch[l], e_u[l], e_u[l], ch[l], 3, !relu_mask);
+        MASKED(d1[l], 10 + 2 * l, (size_t)N * ch[l] * e_d1[l] * e_d1[l]);
+        FN(oracle_conv_valid_fwd)(d1[l], PW(c2e_l[l]), PB(c2e_l[l]), d2[l], N, ch[l], e_d1[l], e_d1[l], ch[l], 3, !relu_mask);
+        MASKED(d2[l], 11 + 2 * l, (size_t)N * ch[l] * e_d2[l] * e_d2[l]);
         dsrc = d2[l]; dcur = e_d2[l];
     }
     const int So = dcur;           /* = S - 184 */
@@ -434,12 +469,12 @@ int FN(oracle_unet_fwd_bwd)(const REAL *const *params, const REAL *x, int N, int
         FN(oracle_conv_valid_bwd)(d2[0], PW(L_FINAL), dlogits, g, GW(L_FINAL), GB(L_FINAL), N, ch[0], So, So, 2, 1);
         for (int l = 0; l < 4; ++l) {
             /* conv_l2e */
-            FN(oracle_relu_bwd)(d2[l], g, (size_t)N * ch[l] * e_d2[l] * e_d2[l]);
+            RELU_BWD(d2[l], g, 11 + 2 * l, (size_t)N * ch[l] * e_d2[l] * e_d2[l]);
             REAL *g1 = ALLOC((size_t)N * ch[l] * e_d1[l] * e_d1[l]);
             FN(oracle_conv_valid_bwd)(d1[l], PW(c2e_l[l]), g, g1, GW(c2e_l[l]), GB(c2e_l[l]), N, ch[l], e_d1[l], e_d1[l], ch[l], 3);
             free(g);
             /* conv_l1e */
-            FN(oracle_relu_bwd)(d1[l], g1, (size_t)N * ch[l] * e_d1[l] * e_d1[l]);
+            RELU_BWD(d1[l], g1, 10 + 2 * l, (size_t)N * ch[l] * e_d1[l] * e_d1[l]);
             REAL *gc = ALLOC((size_t)N * 2 * ch[l] * e_u[l] * e_u[l]);
             FN(oracle_conv_valid_bwd)(cat[l], PW(c1e_l[l]), g1, gc, GW(c1e_l[l]), GB(c1e_l[l]), N, 2 * ch[l], e_u[l], e_u[l], ch[l], 3);
             free(g1);
@@ -458,11 +493,11 @@ int FN(oracle_unet_fwd_bwd)(const REAL *const *params, const REAL *x, int N, int
         }
         /* encoder, level 4 .. 0; g is grad wrt a2[4] (post-ReLU) */
         for (int l = 4; l >= 0; --l) {
-            FN(oracle_relu_bwd)(a2[l], g, (size_t)N * ch[l] * e_a2[l] * e_a2[l]);
+            RELU_BWD(a2[l], g, 2 * l + 1, (size_t)N * ch[l] * e_a2[l] * e_a2[l]);
             REAL *g1 = ALLOC((size_t)N * ch[l] * e_a1[l] * e_a1[l]);
             FN(oracle_conv_valid_bwd)(a1[l], PW(2 * l + 1), g, g1, GW(2 * l + 1), GB(2 * l + 1), N, ch[l], e_a1[l], e_a1[l], ch[l], 3);
             free(g);
-            FN(oracle_relu_bwd)(a1[l], g1, (size_t)N * ch[l] * e_a1[l] * e_a1[l]);
+            RELU_BWD(a1[l], g1, 2 * l, (size_t)N * ch[l] * e_a1[l] * e_a1[l]);
             if (l == 0) {
                 FN(oracle_conv_valid_bwd)(x, PW(0), g1, 0, GW(0), GB(0), N, 1, S, S, ch[0], 3);
                 free(g1);
@@ -482,6 +517,8 @@ int FN(oracle_unet_fwd_bwd)(const REAL *const *params, const REAL *x, int N, int
     for (int l = 0; l < 5; ++l) { free(a1[l]); free(a2[l]); }
     for (int l = 0; l < 4; ++l) { free(t[l]); free(pidx[l]); free(u[l]); free(cat[l]); free(d1[l]); free(d2[l]); }
     return 0;
+#undef MASKED
+#undef RELU_BWD
 #undef PW
 #undef PB
 #undef GW

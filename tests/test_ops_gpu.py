@@ -35,6 +35,14 @@ def nchw(t):   # NHWC cuda -> NCHW cpu fp64
     return t.permute(0, 3, 1, 2).double().cpu()
 
 
+class Keep(list):
+    """Owns the device tensors whose raw pointers are passed to the library."""
+
+    def __call__(self, t):
+        self.append(t)
+        return t
+
+
 def scratch(nbytes):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
 
@@ -46,17 +54,19 @@ def rnd(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32)])
 def test_conv3x3_fwd(hip, B, H, C, K):
+    keep = Keep()
     x = rnd(B, C, H, H, seed=1); w = rnd(K, C, 3, 3, seed=2, scale=0.05); b = rnd(K, seed=3)
     ref = F.relu(F.conv2d(x, w, b))
     y = torch.empty(B, H - 2, H - 2, K, device="cuda")
     sc = scratch(hip.lib().unet_conv3x3_scratch_bytes(C, K))
-    hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(nhwc(x)), H, H, C, 0, None, 0, B, H, H, hip.ptr(w.float().cuda()),
-                                         hip.ptr(b.float().cuda()), K, 1, hip.ptr(y), hip.ptr(sc), hip.stream()), "conv3x3_fwd")
+    hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc(x))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.float().cuda())),
+                                         hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc), hip.stream()), "conv3x3_fwd")
     assert nerr(nchw(y), ref) < TOL
 
 
 @pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128)])
 def test_conv3x3_fwd_virtual_concat(hip, B, Hs, pad, C1, C2, K):
+    keep = Keep()
     """crop_and_concat (network.py:108-127) is never materialised: the conv reads two sources."""
     H = Hs + 2 * pad
     a = rnd(B, C1, Hs, Hs, seed=1); u = rnd(B, C2, H, H, seed=2)
@@ -65,8 +75,8 @@ def test_conv3x3_fwd_virtual_concat(hip, B, Hs, pad, C1, C2, K):
     ref = F.relu(F.conv2d(cat, w, b))
     y = torch.empty(B, H - 2, H - 2, K, device="cuda")
     sc = scratch(hip.lib().unet_conv3x3_scratch_bytes(C1 + C2, K))
-    hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(nhwc(a)), Hs, Hs, C1, pad, hip.ptr(nhwc(u)), C2, B, H, H,
-                                         hip.ptr(w.float().cuda()), hip.ptr(b.float().cuda()), K, 1, hip.ptr(y), hip.ptr(sc),
+    hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc(a))), Hs, Hs, C1, pad, hip.ptr(keep(nhwc(u))), C2, B, H, H,
+                                         hip.ptr(keep(w.float().cuda())), hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc),
                                          hip.stream()), "conv3x3_fwd concat")
     assert nerr(nchw(y), ref) < TOL
 
@@ -74,6 +84,7 @@ def test_conv3x3_fwd_virtual_concat(hip, B, Hs, pad, C1, C2, K):
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True),
                                                       (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False)])
 def test_conv3x3_bwd(hip, B, H, C, K, use_mask, use_add):
+    keep = Keep()
     x = rnd(B, C, H, H, seed=1).requires_grad_(True)
     w = rnd(K, C, 3, 3, seed=2, scale=0.05).requires_grad_(True)
     dz = rnd(B, K, H - 2, H - 2, seed=3)
@@ -87,9 +98,9 @@ def test_conv3x3_bwd(hip, B, H, C, K, use_mask, use_add):
         dx_ref = dx_ref * (mask > 0)
     dx = torch.empty(B, H, H, C, device="cuda"); dw = torch.empty(K, C, 3, 3, device="cuda"); db = torch.empty(K, device="cuda")
     sc = scratch(hip.lib().unet_conv3x3_bwd_scratch_bytes(B, H, H, C, K))
-    hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(nhwc(x.detach())), H, H, C, 0, None, 0, B, H, H, hip.ptr(w.detach().float().cuda()), K,
-                                         hip.ptr(nhwc(dz)), hip.ptr(dx), hip.ptr(nhwc(mask)) if use_mask else None,
-                                         hip.ptr(nhwc(add)) if use_add else None, None, None, hip.ptr(dw), hip.ptr(db),
+    hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(keep(nhwc(x.detach()))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.detach().float().cuda())), K,
+                                         hip.ptr(keep(nhwc(dz))), hip.ptr(dx), hip.ptr(keep(nhwc(mask))) if use_mask else None,
+                                         hip.ptr(keep(nhwc(add))) if use_add else None, None, None, hip.ptr(dw), hip.ptr(db),
                                          hip.ptr(sc), hip.stream()), "conv3x3_bwd")
     assert nerr(nchw(dx), dx_ref) < TOL
     assert nerr(dw, w.grad) < TOL
@@ -98,6 +109,7 @@ def test_conv3x3_bwd(hip, B, H, C, K, use_mask, use_add):
 
 @pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 8, 0, 64, 64)])
 def test_conv3x3_bwd_virtual_concat(hip, B, Hs, pad, C, K):
+    keep = Keep()
     H = Hs + 2 * pad
     a = rnd(B, C, Hs, Hs, seed=1).requires_grad_(True); u = rnd(B, C, H, H, seed=2).requires_grad_(True)
     w = rnd(K, 2 * C, 3, 3, seed=3, scale=0.05).requires_grad_(True)
@@ -106,8 +118,8 @@ def test_conv3x3_bwd_virtual_concat(hip, B, Hs, pad, C, K):
     dx1 = torch.empty(B, Hs, Hs, C, device="cuda"); dx2 = torch.empty(B, H, H, C, device="cuda")
     dw = torch.empty(K, 2 * C, 3, 3, device="cuda"); db = torch.empty(K, device="cuda")
     sc = scratch(hip.lib().unet_conv3x3_bwd_scratch_bytes(B, H, H, 2 * C, K))
-    hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(nhwc(a.detach())), Hs, Hs, C, pad, hip.ptr(nhwc(u.detach())), C, B, H, H,
-                                         hip.ptr(w.detach().float().cuda()), K, hip.ptr(nhwc(dz)), hip.ptr(dx1), None, None,
+    hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(keep(nhwc(a.detach()))), Hs, Hs, C, pad, hip.ptr(keep(nhwc(u.detach()))), C, B, H, H,
+                                         hip.ptr(keep(w.detach().float().cuda())), K, hip.ptr(keep(nhwc(dz))), hip.ptr(dx1), None, None,
                                          hip.ptr(dx2), None, hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()), "conv3x3_bwd concat")
     assert nerr(nchw(dx1), a.grad) < TOL      # pad-backward == crop of the padded gradient
     assert nerr(nchw(dx2), u.grad) < TOL
@@ -117,17 +129,19 @@ def test_conv3x3_bwd_virtual_concat(hip, B, Hs, pad, C, K):
 
 @pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 4, 1024, 512), (3, 17, 64, 32)])
 def test_upconv2_fwd(hip, B, H, Ci, Co):
+    keep = Keep()
     x = rnd(B, Ci, H, H, seed=1); w = rnd(Ci, Co, 2, 2, seed=2, scale=0.05); b = rnd(Co, seed=3)
     ref = F.conv_transpose2d(x, w, b, stride=2)
     y = torch.empty(B, 2 * H, 2 * H, Co, device="cuda")
     sc = scratch(hip.lib().unet_upconv2_scratch_bytes(B, H, H, max(Ci, 64), max(Co, 64)))
-    hip.check(hip.lib().unet_upconv2_fwd(hip.ptr(nhwc(x)), B, H, H, Ci, hip.ptr(w.float().cuda()), hip.ptr(b.float().cuda()), Co,
+    hip.check(hip.lib().unet_upconv2_fwd(hip.ptr(keep(nhwc(x))), B, H, H, Ci, hip.ptr(keep(w.float().cuda())), hip.ptr(keep(b.float().cuda())), Co,
                                          hip.ptr(y), hip.ptr(sc), hip.stream()), "upconv2_fwd")
     assert nerr(nchw(y), ref) < TOL
 
 
 @pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 18, 128, 64)])
 def test_upconv2_bwd(hip, B, H, Ci, Co):
+    keep = Keep()
     x = rnd(B, Ci, H, H, seed=1).clamp_min(0).requires_grad_(True)     # the producer's ReLU output
     w = rnd(Ci, Co, 2, 2, seed=2, scale=0.05).requires_grad_(True)
     dy = rnd(B, Co, 2 * H, 2 * H, seed=3)
@@ -136,7 +150,7 @@ def test_upconv2_bwd(hip, B, H, Ci, Co):
     dx = torch.empty(B, H, H, Ci, device="cuda"); dw = torch.empty(Ci, Co, 2, 2, device="cuda"); db = torch.empty(Co, device="cuda")
     sc = scratch(hip.lib().unet_upconv2_scratch_bytes(B, H, H, Ci, Co))
     xd = nhwc(x.detach())
-    hip.check(hip.lib().unet_upconv2_bwd(hip.ptr(xd), B, H, H, Ci, hip.ptr(w.detach().float().cuda()), Co, hip.ptr(nhwc(dy)),
+    hip.check(hip.lib().unet_upconv2_bwd(hip.ptr(xd), B, H, H, Ci, hip.ptr(keep(w.detach().float().cuda())), Co, hip.ptr(keep(nhwc(dy))),
                                          hip.ptr(dx), hip.ptr(xd), hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()), "upconv2_bwd")
     assert nerr(nchw(dx), dx_ref) < TOL
     assert nerr(dw, w.grad) < TOL
@@ -144,6 +158,7 @@ def test_upconv2_bwd(hip, B, H, Ci, Co):
 
 
 def test_maxpool2_fwd_bwd_exact(hip):
+    keep = Keep()
     """Pool is a selection: bit-exact, including first-max-wins ties (all-zero windows after ReLU)."""
     B, H, Cc = 2, 12, 64
     pre = rnd(B, Cc, H, H, seed=1).clamp_min(0).float()
@@ -156,12 +171,13 @@ def test_maxpool2_fwd_bwd_exact(hip):
     y = torch.empty(B, H // 2, H // 2, Cc, device="cuda"); dpre = torch.empty(B, H, H, Cc, device="cuda")
     xd = nhwc(pre)
     hip.check(hip.lib().unet_maxpool2_fwd(hip.ptr(xd), hip.ptr(y), B, H, H, Cc, hip.stream()))
-    hip.check(hip.lib().unet_maxpool2_bwd(hip.ptr(xd), hip.ptr(nhwc(dy)), hip.ptr(dpre), B, H, H, Cc, hip.stream()))
+    hip.check(hip.lib().unet_maxpool2_bwd(hip.ptr(xd), hip.ptr(keep(nhwc(dy))), hip.ptr(dpre), B, H, H, Cc, hip.stream()))
     assert torch.equal(y.permute(0, 3, 1, 2).cpu(), y_ref.detach())
     assert torch.equal(dpre.permute(0, 3, 1, 2).cpu(), p.grad)
 
 
 def test_head1x1_fwd_bwd(hip):
+    keep = Keep()
     B, H, Cc = 2, 37, 64
     x = rnd(B, Cc, H, H, seed=1).clamp_min(0).requires_grad_(True)
     w = rnd(2, Cc, 1, 1, seed=2, scale=0.1).requires_grad_(True); b = rnd(2, seed=3)
@@ -170,12 +186,12 @@ def test_head1x1_fwd_bwd(hip):
     ref.backward(dl)
     logits = torch.empty(B, 2, H, H, device="cuda")
     xd = nhwc(x.detach())
-    hip.check(hip.lib().unet_head1x1_fwd(hip.ptr(xd), B, H, H, Cc, hip.ptr(w.detach().float().cuda()), hip.ptr(b.float().cuda()),
+    hip.check(hip.lib().unet_head1x1_fwd(hip.ptr(xd), B, H, H, Cc, hip.ptr(keep(w.detach().float().cuda())), hip.ptr(keep(b.float().cuda())),
                                          hip.ptr(logits), hip.stream()))
     assert nerr(logits, ref) < TOL
     dz = torch.empty(B, H, H, Cc, device="cuda"); dw = torch.empty(2, Cc, 1, 1, device="cuda"); db = torch.empty(2, device="cuda")
     sc = scratch(hip.lib().unet_head1x1_bwd_scratch_bytes(B, H, H, Cc))
-    hip.check(hip.lib().unet_head1x1_bwd(hip.ptr(xd), B, H, H, Cc, hip.ptr(w.detach().float().cuda()), hip.ptr(dl.float().cuda()),
+    hip.check(hip.lib().unet_head1x1_bwd(hip.ptr(xd), B, H, H, Cc, hip.ptr(keep(w.detach().float().cuda())), hip.ptr(keep(dl.float().cuda())),
                                          hip.ptr(dz), hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()))
     assert nerr(nchw(dz), x.grad * (x.detach() > 0)) < TOL
     assert nerr(dw, w.grad) < TOL
@@ -183,23 +199,25 @@ def test_head1x1_fwd_bwd(hip):
 
 
 def test_conv1ch_fwd_bwd_vs_c_oracle(hip):
+    keep = Keep()
     from oracle import oracle_c
     B, S, K = 2, 45, 64
     x = rnd(B, 1, S, S, seed=1).float(); w = rnd(K, 1, 3, 3, seed=2).float(); b = rnd(K, seed=3).float()
     ref = oracle_c.conv_valid_fwd(x.double().numpy(), w.double().numpy(), b.double().numpy(), True)
     y = torch.empty(B, S - 2, S - 2, K, device="cuda")
-    hip.check(hip.lib().unet_conv1ch_fwd(hip.ptr(x.cuda()), B, S, hip.ptr(w.cuda()), hip.ptr(b.cuda()), K, hip.ptr(y), hip.stream()))
+    hip.check(hip.lib().unet_conv1ch_fwd(hip.ptr(keep(x.cuda())), B, S, hip.ptr(keep(w.cuda())), hip.ptr(keep(b.cuda())), K, hip.ptr(y), hip.stream()))
     assert nerr(nchw(y), torch.from_numpy(ref)) < TOL
     dz = rnd(B, K, S - 2, S - 2, seed=4).float()
     _, dw_ref, db_ref = oracle_c.conv_valid_bwd(x.double().numpy(), w.double().numpy(), dz.double().numpy(), need_dx=False)
     dw = torch.empty(K, 1, 3, 3, device="cuda"); db = torch.empty(K, device="cuda")
     sc = scratch(hip.lib().unet_conv1ch_bwd_scratch_bytes(B, S, K))
-    hip.check(hip.lib().unet_conv1ch_bwd(hip.ptr(x.cuda()), B, S, K, hip.ptr(nhwc(dz)), hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()))
+    hip.check(hip.lib().unet_conv1ch_bwd(hip.ptr(keep(x.cuda())), B, S, K, hip.ptr(keep(nhwc(dz))), hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()))
     assert nerr(dw, torch.from_numpy(dw_ref)) < TOL
     assert nerr(db, torch.from_numpy(db_ref)) < TOL
 
 
 def test_step_side_kernels(hip, golden_dir):
+    keep = Keep()
     import os
     from oracle import oracle_c, prng
     L = hip.lib()
