@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="tiles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write per-launch timings (CSV) of the timed region here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -155,7 +156,8 @@ def main():
                                "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
                                "gflop_per_launch": fl0 / max(n0, 1) / 1e9,
                                "share_of_step_time": ms0 / (dt * 1e3)}
-            ms1, n1, fl1 = fam["wgrad_f32"]
+            if args.dump_launches:
+                _hip.check(L.unet_profile_dump(args.dump_launches.encode()))
             out["kernels"] = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
                                   "tflops": (v[2] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[2] > 0 else None)}
                               for k, v in fam.items()}

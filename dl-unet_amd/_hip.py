@@ -34,6 +34,7 @@ _SIGS = {
     "unet_profile_enable": (C.c_int, [C.c_int]),
     "unet_profile_reset": (C.c_int, []),
     "unet_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "unet_profile_dump": (C.c_int, [C.c_char_p]),
     "unet_bce_scratch_bytes": (C.c_size_t, [C.c_size_t]),
     "unet_bce_logits": (C.c_int, [vp, vp, vp, C.c_long, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
                                   vp, vp, C.c_float, vp, vp]),

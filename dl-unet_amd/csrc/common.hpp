@@ -27,7 +27,7 @@ const float *zero_page();          // 4 KiB of device zeros on the current devic
     } while (0)
 
 // per-family event timing (prof.hip); family 0 = igemm, 1 = wgrad, 2 = wgrad reduce
-void prof_begin(int family, double flops, hipStream_t st);
+void prof_begin(int family, double flops, hipStream_t st, const char *tag = nullptr);
 void prof_end(hipStream_t st);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -81,6 +81,7 @@ struct WgradP {
     int ywin0, ywin1, xwin0, xwin1;    // Y-domain window whose taps can touch X
     int Ci, Cj;                        // multiples of 64
     float *out; long si, sj, st;       // final gradient tensor strides (elements)
+    float *db;                         // optional fused bias gradient db[yc0 + j] = sum Y (needs the full window)
     float *slab; size_t slab_bytes;    // scratch for partials
     const float *zeros;
 };

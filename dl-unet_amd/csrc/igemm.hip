@@ -16,6 +16,7 @@
 // 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE address and on the fragment
 // read, which makes the ds_read_b128 fragment reads bank-conflict free.
 #include "common.hpp"
+#include <cstdio>
 
 namespace unet {
 
@@ -265,7 +266,9 @@ static int launch_cfg(const IgemmP &p, hipStream_t st)
     IgemmP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Nn, BN);
-    prof_begin(0, igemm_alg_flops(p), st);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "igemm<%d;%d;%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
+    prof_begin(0, igemm_alg_flops(p), st, tag);
     hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());

@@ -162,7 +162,7 @@ static IgemmP conv_dgrad_desc(const float *dz, int Ho, int Wo, int K, int B, int
 }
 
 static WgradP conv_wgrad_desc(const float *X, int XH, int XC, int xpad, const float *dz, int Ho, int K, int B,
-                              float *dw, int Ctot, int c_off, float *slab, size_t slab_bytes)
+                              float *dw, int Ctot, int c_off, float *slab, size_t slab_bytes, float *db = nullptr)
 {
     WgradP p{};
     p.X = X; p.XH = XH; p.XW = XH; p.XC = XC; p.xc0 = 0; p.xpad = xpad;
@@ -173,7 +173,7 @@ static WgradP conv_wgrad_desc(const float *X, int XH, int XC, int xpad, const fl
     p.ywin0 = w0; p.ywin1 = w1; p.xwin0 = w0; p.xwin1 = w1;
     p.Ci = XC; p.Cj = K;
     p.out = dw ? dw + (size_t)c_off * 9 : nullptr; p.si = 9; p.sj = (long)Ctot * 9; p.st = 1;
-    p.slab = slab; p.slab_bytes = slab_bytes;
+    p.slab = slab; p.slab_bytes = slab_bytes; p.db = db;
     return p;
 }
 
@@ -401,7 +401,7 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
 
 /* Debug/introspection: byte offset and element count of a named workspace buffer, e.g. "a1_0",
  * "a2_4", "t_2", "u_3", "d1_0", "d2_3", and with training=1 "g_a1_0", "g_a2_4", "g_t_1", "g_ts_1",
- * "g_u_2", "g_d1_3", "g_d2_3", "xin".  Tensors are NHWC [B,e,e,C]; *extent/*channels describe them. */
+ * "g_u_2", "g_d1_3", "g_d2_3", "xin".  Tensors are NHWC [B,e,e,C]; extent and channels describe them. */
 int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const char *name,
                       size_t *offset, int *extent, int *channels)
 {
@@ -474,9 +474,8 @@ static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const 
         IgemmP d = conv_dgrad_desc(dz, Ho, Ho, K, B, XH, 0, WS(pl.wt_bwd[layer]), C, dx, mask, add);
         if ((rc = launch_igemm(d, st))) return rc;
     }
-    WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes);
-    if ((rc = launch_wgrad(w, st))) return rc;
-    return bias_grad(dz, (size_t)B * Ho * Ho, K, GRAD(2 * layer + 1), WS(pl.small), st);
+    WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes, GRAD(2 * layer + 1));
+    return launch_wgrad(w, st);
 }
 
 int unet_backward_stage(unet_handle *h, int stage, const void *const *params, const void *dlogits, void *const *grads,
@@ -523,9 +522,8 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
                                          GRAD(2 * lay), 2 * ch[l], 0, WS(pl.slab), pl.slab_bytes);
             if ((rc = launch_wgrad(ws_, st))) return rc;
             WgradP wu = conv_wgrad_desc(WS(pl.u[l]), pl.eu[l], ch[l], 0, WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
-                                        GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes);
+                                        GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes, GRAD(2 * lay + 1));
             if ((rc = launch_wgrad(wu, st))) return rc;
-            if ((rc = bias_grad(WS(pl.g_d1[l]), (size_t)B * pl.ed1[l] * pl.ed1[l], ch[l], GRAD(2 * lay + 1), WS(pl.small), st))) return rc;
         }
         // upconv_l: input is d2[l+1] (or a2[4]); its dgrad is masked by that ReLU output
         {
@@ -643,15 +641,21 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
             if ((rc = launch_igemm(d, st))) return rc;
         }
     }
+    bool db_done = false;
     if (dw) {
-        WgradP w1 = conv_wgrad_desc((const float *)x1, H1, C1, pad1, (const float *)dz, Ho, K, B, (float *)dw, C, 0, slab, slab_bytes);
+        // the bias gradient rides on whichever weight-gradient launch covers the full dz window
+        const bool full1 = !x2 && pad1 == 0;
+        WgradP w1 = conv_wgrad_desc((const float *)x1, H1, C1, pad1, (const float *)dz, Ho, K, B, (float *)dw, C, 0, slab, slab_bytes,
+                                    full1 ? (float *)db : nullptr);
         if ((rc = launch_wgrad(w1, st))) return rc;
+        db_done = full1 && db;
         if (x2) {
-            WgradP w2 = conv_wgrad_desc((const float *)x2, H, C2, 0, (const float *)dz, Ho, K, B, (float *)dw, C, C1, slab, slab_bytes);
+            WgradP w2 = conv_wgrad_desc((const float *)x2, H, C2, 0, (const float *)dz, Ho, K, B, (float *)dw, C, C1, slab, slab_bytes, (float *)db);
             if ((rc = launch_wgrad(w2, st))) return rc;
+            db_done = db != nullptr;
         }
     }
-    if (db && (rc = bias_grad((const float *)dz, (size_t)B * Ho * Ho, K, (float *)db, small, st))) return rc;
+    if (db && !db_done && (rc = bias_grad((const float *)dz, (size_t)B * Ho * Ho, K, (float *)db, small, st))) return rc;
     return 0;
 }
 

@@ -3,12 +3,14 @@
 #include "common.hpp"
 #include "../../include/unet_hip.h"
 
+#include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
 namespace unet {
 
-struct ProfRec { hipEvent_t a, b; int family; double flops; };
+struct ProfRec { hipEvent_t a, b; int family; double flops; char tag[96]; };
 static std::mutex g_mu;
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
@@ -22,11 +24,12 @@ static hipEvent_t get_event()
     return e;
 }
 
-void prof_begin(int family, double flops, hipStream_t st)
+void prof_begin(int family, double flops, hipStream_t st, const char *tag)
 {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    ProfRec r{get_event(), get_event(), family, flops};
+    ProfRec r{get_event(), get_event(), family, flops, {0}};
+    if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); }
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -75,6 +78,23 @@ int unet_profile_read(int family, double *ms_total, long *launches, double *flop
     if (ms_total) *ms_total = ms;
     if (launches) *launches = n;
     if (flops_total) *flops_total = fl;
+    return 0;
+}
+
+/* writes one line per recorded launch: family,ms,gflop,tag */
+int unet_profile_dump(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    FILE *f = fopen(path, "w");
+    if (!f) { set_error("unet_profile_dump: cannot open %s", path); return -2; }
+    fprintf(f, "family,ms,gflop,tag\n");
+    for (auto &r : g_recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        fprintf(f, "%d,%.6f,%.6f,%s\n", r.family, t, r.flops / 1e9, r.tag);
+    }
+    fclose(f);
     return 0;
 }
 

@@ -14,6 +14,7 @@
 // wave accumulates T 32x32 MFMA tiles (v_mfma_f32_32x32x2_f32, K = a pair of pixels).  Partial tiles
 // go to a slab and a second kernel reduces them in a fixed order (deterministic, no atomics).
 #include "common.hpp"
+#include <cstdio>
 
 namespace unet {
 
@@ -26,6 +27,7 @@ constexpr int PWMAX = 32;     // pixels per strip (MFMA K = pixel pairs)
 struct WgradK {               // kernel-side copy with the derived decomposition
     WgradP p;
     int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
+    size_t pstride;                    // floats per partition in the slab: T*Ci*Cj weights + Cj bias partials
 };
 
 template <int TY, int TX, int S>
@@ -42,7 +44,7 @@ struct WgradGeom {
 };
 
 template <int TY, int TX, int S>
-__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradK k)
+__global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(const WgradK k)
 {
     using G = WgradGeom<TY, TX, S>;
     constexpr int T = G::T;
@@ -113,6 +115,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradK k)
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // fused bias gradient: the i-tile-0 workgroups also sum their Y strip over pixels (db[j] = sum dz)
+    const bool do_bias = p.db != nullptr && it == 0;
+    float bsum = 0.f;
+    const int bch = tid & 63, bpg = tid >> 6;
 
     const int l31 = lane & 31, lh = lane >> 5;
     const int a_lane = (wi * 32 + l31) * 4;      // byte offset of this lane's X channel within a pixel
@@ -125,6 +131,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradK k)
             const int cur = (y - ya) & 1;
             if (y + 1 < yb) stage_step(y + 1, cur ^ 1, TY - S, S);   // rows new to the next step
             const int xr0 = (y + p.oy0) * S - p.xpad;
+            if (do_bias) {
+                const float *yb_ = (const float *)(ys + cur * G::YBUF) + bch;
+                for (int px = bpg; px < pwv; px += 4) bsum += yb_[px * 64];
+            }
             const unsigned char *yrow = ys + cur * G::YBUF + b_lane;
             for (int q = 0; q < npairs; ++q) {
                 const int pix = 2 * q + lh;
@@ -143,8 +153,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradK k)
         }
     }
 
-    // partial tile -> slab[P][t][Ci][Cj]
-    float *slab = p.slab + (size_t)P * T * p.Ci * p.Cj;
+    // partial tile -> slab[P][t][Ci][Cj] (+ [Cj] bias partials behind it)
+    float *slab = p.slab + (size_t)P * k.pstride;
+    if (do_bias) {
+        float *red = (float *)smem;             // all LDS reads of the loop are behind its last barrier
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) slab[(size_t)T * p.Ci * p.Cj + jt * 64 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -156,26 +172,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradK k)
     }
 }
 
-// out[i*si + j*sj + t*st] = sum_P slab[P][t][i][j]   (fixed summation order)
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, int T, int Ci, int Cj,
-                                    float *__restrict__ out, long si, long sj, long st)
+// out[i*si + j*sj + t*st] = sum_P slab[P][t][i][j]  and  db[j] = sum_P slab[P][T*Ci*Cj + j], in a fixed order.
+// Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
+// even when the output is tiny (64x64x9) and the partition count is in the thousands.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, size_t pstride, int T, int Ci, int Cj,
+                                                           float *__restrict__ out, long si, long sj, long st, float *__restrict__ db)
 {
-    const size_t total = (size_t)T * Ci * Cj;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t nw = (size_t)T * Ci * Cj;
+    const size_t total = nw + (db ? (size_t)Cj : 0);
+    const int lane_e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    __shared__ float red[256];
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t e = base + lane_e;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int P = 0;
-        for (; P + 4 <= nP; P += 4) {
-            s0 += slab[(size_t)P * total + e];
-            s1 += slab[(size_t)(P + 1) * total + e];
-            s2 += slab[(size_t)(P + 2) * total + e];
-            s3 += slab[(size_t)(P + 3) * total + e];
+        if (e < total) {
+            const float *src = slab + e;
+            int P = grp;
+            for (; P + 12 < nP; P += 16) {
+                s0 += src[(size_t)P * pstride];
+                s1 += src[(size_t)(P + 4) * pstride];
+                s2 += src[(size_t)(P + 8) * pstride];
+                s3 += src[(size_t)(P + 12) * pstride];
+            }
+            for (; P < nP; P += 4) s0 += src[(size_t)P * pstride];
         }
-        for (; P < nP; ++P) s0 += slab[(size_t)P * total + e];
-        const int j = (int)(e % Cj);
-        const size_t ti = e / Cj;
-        const int i = (int)(ti % Ci);
-        const int t = (int)(ti / Ci);
-        out[i * si + j * sj + t * st] = (s0 + s1) + (s2 + s3);
+        red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (grp == 0 && e < total) {
+            const float v = (red[lane_e] + red[lane_e + 64]) + (red[lane_e + 128] + red[lane_e + 192]);
+            if (e < nw) {
+                const int j = (int)(e % Cj);
+                const size_t ti = e / Cj;
+                const int i = (int)(ti % Ci);
+                const int t = (int)(ti / Ci);
+                out[i * si + j * sj + t * st] = v;
+            } else {
+                db[e - nw] = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -189,21 +224,38 @@ static void decompose(const WgradP &p, WgradK &k)
     k.nstrips = cdiv(wx, pw);
     k.ntile_i = p.Ci / 64;
     k.ntile_j = p.Cj / 64;
-    // aim for ~2048 workgroups, but at least 8 rows per workgroup to amortise the slab write
+    // Row-chunking: every workgroup takes the same time, so pick the chunk count whose total workgroup
+    // count fills whole rounds of the resident slots (256 CUs x 3 workgroups for the 3x3 kernel), with
+    // a mild preference for fewer partitions (each one costs a slab write + read in the reduce) and at
+    // least 8 rows per workgroup to amortise that write.
     const long base = (long)p.NB * k.nstrips * k.ntile_i * k.ntile_j;
-    int nchunks = (int)((2048 + base - 1) / base);
-    if (nchunks < 1) nchunks = 1;
-    int rows = cdiv(wy, nchunks);
-    if (rows < 8) rows = wy < 8 ? wy : 8;
+    const int slots = 256 * (p.TY == 3 ? 3 : 2);
+    int best_n = 1;
+    double best_score = -1e30;
+    const int max_chunks = wy >= 8 ? wy / 8 : 1;
+    for (int n = 1; n <= max_chunks; ++n) {
+        const int rows_n = cdiv(wy, n);
+        const int n_eff = cdiv(wy, rows_n);
+        if (n_eff != n) continue;                                 // same decomposition as a smaller n
+        const long nblk = base * n;
+        const long rounds = (nblk + slots - 1) / slots;
+        // the last chunk may be short: count work in rows, not workgroups
+        const double eff = (double)base * wy / ((double)rounds * slots * rows_n);
+        const double score = eff - 0.015 * (double)rounds;
+        if (score > best_score) { best_score = score; best_n = n; }
+        if (nblk > 8L * slots) break;
+    }
+    int rows = cdiv(wy, best_n);
     k.rows_per_chunk = rows;
     k.nchunks = cdiv(wy, rows);
+    k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + p.Cj, 64);
 }
 
 size_t wgrad_slab_need(const WgradP &p)
 {
     WgradK k{};
     decompose(p, k);
-    return (size_t)p.NB * k.nchunks * k.nstrips * p.TY * p.TX * p.Ci * p.Cj * sizeof(float);
+    return (size_t)p.NB * k.nchunks * k.nstrips * k.pstride * sizeof(float);
 }
 
 static double wgrad_alg_flops(const WgradP &p)
@@ -226,7 +278,10 @@ static int launch_wgrad_t(const WgradK &k, int nP, hipStream_t st)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         attr_done = true;
     }
-    prof_begin(1, wgrad_alg_flops(k.p), st);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d> Ci=%d Cj=%d Y=%dx%d win=%d nP=%d pw=%d rows=%d", TY, TX, S, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
+             k.p.ywin1 - k.p.ywin0, nP, k.pw, k.rows_per_chunk);
+    prof_begin(1, wgrad_alg_flops(k.p), st, tag);
     hipLaunchKernelGGL(kern, dim3(nP * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
     prof_end(st);
     HIP_TRY(hipGetLastError());
@@ -246,18 +301,19 @@ int launch_wgrad(WgradP p, hipStream_t st)
     decompose(p, k);
     const int nP = p.NB * k.nchunks * k.nstrips;
     const int T = p.TY * p.TX;
-    const size_t need = (size_t)nP * T * p.Ci * p.Cj * sizeof(float);
+    const size_t need = (size_t)nP * k.pstride * sizeof(float);
     ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
     int rc;
     if (p.TY == 3 && p.TX == 3 && p.stride == 1) rc = launch_wgrad_t<3, 3, 1>(k, nP, st);
     else if (p.TY == 2 && p.TX == 2 && p.stride == 2) rc = launch_wgrad_t<2, 2, 2>(k, nP, st);
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
-    const size_t total = (size_t)T * p.Ci * p.Cj;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");
+    const size_t total = (size_t)T * p.Ci * p.Cj + (p.db ? p.Cj : 0);
+    size_t blocks = (total + 63) / 64;
+    if (blocks > 16384) blocks = 16384;
     prof_begin(2, 0.0, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, nP, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st, p.db);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -104,6 +104,8 @@ int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const ch
 int unet_profile_enable(int on);
 int unet_profile_reset(void);
 int unet_profile_read(int family, double *ms_total, long *launches, double *flops_total);
+/* one CSV line per recorded launch: family,ms,gflop,tag (shape of the launch) */
+int unet_profile_dump(const char *path);
 
 /* ---- step-side kernels (L1-L3) -------------------------------------------------------------
  * L1 replaces nn.BCEWithLogitsLoss(weight=w)(preds, ll) + its backward (trainer.py:63-77).
