@@ -99,18 +99,20 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float *__restr
     }
 }
 
-// out: dw[k][t] (t<9) and db[k] from partial[nb][10][K]
-__global__ void conv1ch_wgrad_reduce_kernel(const float *__restrict__ partial, int nb, int K,
-                                            float *__restrict__ dw, float *__restrict__ db)
+// out: dw[k][t] (t<9) and db[k] from partial[nb][10][K]; one wave per output, lanes over the partials
+__global__ __launch_bounds__(256) void conv1ch_wgrad_reduce_kernel(const float *__restrict__ partial, int nb, int K,
+                                                                   float *__restrict__ dw, float *__restrict__ db)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= 10 * K) return;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 2 <= nb; b += 2) { s0 += partial[(size_t)b * 10 * K + e]; s1 += partial[(size_t)(b + 1) * 10 * K + e]; }
-    if (b < nb) s0 += partial[(size_t)b * 10 * K + e];
-    const int t = e / K, kk = e - t * K;
-    if (t < 9) { if (dw) dw[kk * 9 + t] = s0 + s1; } else if (db) db[kk] = s0 + s1;
+    float s = 0.f;
+    for (int b = lane; b < nb; b += 64) s += partial[(size_t)b * 10 * K + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) {
+        const int t = e / K, kk = e - t * K;
+        if (t < 9) { if (dw) dw[kk * 9 + t] = s; } else if (db) db[kk] = s;
+    }
 }
 
 // ============================================================================================
@@ -196,16 +198,16 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float *__restric
     }
 }
 
-__global__ void head1x1_bwd_reduce_kernel(const float *__restrict__ partial, int nb, int C,
-                                          float *__restrict__ dw, float *__restrict__ db)
+__global__ __launch_bounds__(256) void head1x1_bwd_reduce_kernel(const float *__restrict__ partial, int nb, int C,
+                                                                 float *__restrict__ dw, float *__restrict__ db)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= 2 * C + 2) return;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 2 <= nb; b += 2) { s0 += partial[(size_t)b * (2 * C + 2) + e]; s1 += partial[(size_t)(b + 1) * (2 * C + 2) + e]; }
-    if (b < nb) s0 += partial[(size_t)b * (2 * C + 2) + e];
-    if (e < 2 * C) { if (dw) dw[e] = s0 + s1; } else if (db) db[e - 2 * C] = s0 + s1;
+    float s = 0.f;
+    for (int b = lane; b < nb; b += 64) s += partial[(size_t)b * (2 * C + 2) + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) { if (e < 2 * C) { if (dw) dw[e] = s; } else if (db) db[e - 2 * C] = s; }
 }
 
 // ============================================================================================
@@ -496,9 +498,10 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(const SgdTable tb, fl
             while (tb.start[t + 1] <= e) ++t;
             const unsigned long long o = e - tb.start[t];
             const float g = tb.g[t][o];
-            const float b = first ? g : fmaf(mu, tb.b[t][o], g);
+            // separately rounded multiply and add, like the reference's buf.mul_(mu).add_(g); p.add_(buf, alpha=-lr)
+            const float b = first ? g : __fadd_rn(__fmul_rn(mu, tb.b[t][o]), g);
             tb.b[t][o] = b;
-            tb.p[t][o] -= lr * b;
+            tb.p[t][o] = __fsub_rn(tb.p[t][o], __fmul_rn(lr, b));
         }
     }
 }
@@ -521,7 +524,7 @@ int unet_conv1ch_fwd(const void *x, int B, int S, const void *w, const void *bia
     return 0;
 }
 
-static int conv1ch_bwd_blocks(int B, int S) { const size_t npix = (size_t)B * (S - 2) * (S - 2); return grid_for(npix, 16 * 64, 2048); }
+static int conv1ch_bwd_blocks(int B, int S) { const size_t npix = (size_t)B * (S - 2) * (S - 2); return grid_for(npix, 16 * 64, 512); }
 size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K) { return (size_t)conv1ch_bwd_blocks(B, S) * 10 * K * sizeof(float); }
 int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *dw, void *db, void *scratch, void *stream)
 {
@@ -530,7 +533,7 @@ int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *d
     hipStream_t st = (hipStream_t)stream;
     if (K == 64) hipLaunchKernelGGL(conv1ch_wgrad_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)dz, (float *)scratch, B, S);
     else hipLaunchKernelGGL(conv1ch_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)dz, (float *)scratch, B, S);
-    hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(cdiv(10 * K, 256)), dim3(256), 0, st, (const float *)scratch, nb, K, (float *)dw, (float *)db);
+    hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(cdiv(10 * K, 4)), dim3(256), 0, st, (const float *)scratch, nb, K, (float *)dw, (float *)db);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -547,7 +550,7 @@ int unet_head1x1_fwd(const void *x, int B, int H, int W, int C, const void *w, c
     return 0;
 }
 
-static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 2048); }
+static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 512); }
 size_t unet_head1x1_bwd_scratch_bytes(int B, int H, int W, int C) { return (size_t)head_bwd_blocks(B, H, W) * (2 * C + 2) * sizeof(float); }
 int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, const void *dlogits, void *dz,
                      void *dw, void *db, void *scratch, void *stream)
@@ -557,7 +560,7 @@ int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, c
     hipStream_t st = (hipStream_t)stream;
     if (C == 64) hipLaunchKernelGGL(head1x1_bwd_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
     else hipLaunchKernelGGL(head1x1_bwd_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
-    hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 256)), dim3(256), 0, st, (const float *)scratch, nb, C, (float *)dw, (float *)db);
+    hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 4)), dim3(256), 0, st, (const float *)scratch, nb, C, (float *)dw, (float *)db);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -1,7 +1,7 @@
 // igemm.hip — fp32 implicit-GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
 //
 // One kernel family serves every dense contraction on the path:
-//   conv3x3 fwd (+bias+ReLU, virtual zero-pad-concat of two sources)   network.py:131-188
+//   conv3x3 fwd (+bias+ReLU, virtual zero-pad/crop-concat of two sources)   network.py:131-188
 //   conv3x3 dgrad (full correlation with the flipped filter, + ReLU' mask / + skip gradient)
 //   up-conv 2x2 s2 fwd (GEMM + scatter store) and dgrad (4 taps, stride 2)   network.py:159-183
 //
@@ -15,14 +15,98 @@
 // round trip), double buffered, one barrier per K step.  LDS rows are 128 B (32 floats of K); the
 // 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE address and on the fragment
 // read, which makes the ds_read_b128 fragment reads bank-conflict free.
+//
 #include "common.hpp"
 #include <cstdio>
+#include <cstdlib>
 
 namespace unet {
+
+int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st);
 
 #define GLDS16(gptr, lptr)                                                                    \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// ---- epilogue: per-row destination offsets through
+// LDS, then bias / add / ReLU / mask / store.  Rows past M get row M-1's (valid) offset so every
+// mask/add load is issued unconditionally and back to back; only the store is predicated.
+template <int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid,
+                                               unsigned *rowoff /* LDS, BM entries */)
+{
+    constexpr int WN = BN / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (tid < BM) {
+        int m = m0 + tid;
+        m = m < p.M ? m : p.M - 1;
+        unsigned off;
+        if (!p.scatter) {
+            off = (unsigned)m * (unsigned)p.DC;
+        } else {
+            const int ohw = p.OH * p.OW;
+            const int img = m / ohw;
+            const int rem = m - img * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int n_raw = n0 + wn * 64 + tn * 32 + l31;
+        const bool n_ok = n_raw < p.Nn;
+        const int n = n_ok ? n_raw : p.Nn - 1;
+        int coloff, bidx;
+        if (!p.scatter) {
+            coloff = p.dn0 + n;
+            bidx = p.cout ? n % p.cout : n;
+        } else {
+            const int ab = n / p.cout;
+            bidx = n - ab * p.cout;
+            coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + bidx;
+        }
+        const float bv = p.bias ? p.bias[bidx] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            size_t o[16];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                o[r] = (size_t)rowoff[row] + (size_t)coloff;
+                v[r] = acc[tm][tn][r] + bv;
+            }
+            if (p.add) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = p.add[o[r]];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += t[r];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            if (p.mask) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = p.mask[o[r]];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m0 + row < p.M) p.dst[o[r]] = v[r];
+            }
+        }
+    }
+}
 
 template <int BM, int BN, bool PAD>
 __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
@@ -162,83 +246,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
         __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
     }
 
-    // ---- epilogue: per-row destination offsets through LDS, then bias / add / ReLU / mask / store.
-    // Rows past M get row M-1's (valid) offset so every mask/add load can be issued unconditionally
-    // and back to back; only the store is predicated.
-    unsigned *rowoff = (unsigned *)smem;
-    if (tid < BM) {
-        int m = m0 + tid;
-        m = m < p.M ? m : p.M - 1;
-        unsigned off;
-        if (!p.scatter) {
-            off = (unsigned)m * (unsigned)p.DC;
-        } else {
-            const int ohw = p.OH * p.OW;
-            const int img = m / ohw;
-            const int rem = m - img * ohw;
-            const int oy = rem / p.OW;
-            const int ox = rem - oy * p.OW;
-            off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
-        }
-        rowoff[tid] = off;
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int n_raw = n0 + wn * 64 + tn * 32 + l31;
-        const bool n_ok = n_raw < p.Nn;
-        const int n = n_ok ? n_raw : p.Nn - 1;
-        int coloff, bidx;
-        if (!p.scatter) {
-            coloff = p.dn0 + n;
-            bidx = p.cout ? n % p.cout : n;
-        } else {
-            const int ab = n / p.cout;
-            bidx = n - ab * p.cout;
-            coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + bidx;
-        }
-        const float bv = p.bias ? p.bias[bidx] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            size_t o[16];
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                o[r] = (size_t)rowoff[row] + (size_t)coloff;
-                v[r] = acc[tm][tn][r] + bv;
-            }
-            if (p.add) {
-                float t[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = p.add[o[r]];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += t[r];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-            }
-            if (p.mask) {
-                float t[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = p.mask[o[r]];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m0 + row < p.M) p.dst[o[r]] = v[r];
-            }
-        }
-    }
+    igemm_epilogue<BM, BN>(p, acc, m0, n0, tid, (unsigned *)smem);
 }
 
 // Algorithmic FLOPs of one launch: 2 * (in-bounds (pixel, tap) pairs) * channels * N.  Taps that fall
 // into the virtual zero padding are not counted (they are work the tiling does, not work the op needs).
-static double igemm_alg_flops(const IgemmP &p)
+double igemm_alg_flops(const IgemmP &p)
 {
     double total = 0.0;
     const int TYn = p.T / p.TX;
@@ -299,6 +312,8 @@ int launch_igemm(IgemmP p, hipStream_t st)
         ARG_CHECK((size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C < 0x7FFFFFFFull, "igemm: source exceeds 31-bit element offsets");
     p.zeros = zero_page();
     if (!p.zeros) return -2;
+    static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();
+    if (gen == 2) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
     if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true>(p, st) : launch_cfg<128, 128, false>(p, st);
     return pad ? launch_cfg<256, 64, true>(p, st) : launch_cfg<256, 64, false>(p, st);
 }

@@ -249,6 +249,7 @@ def test_step_side_kernels(hip, golden_dir):
     hip.check(L.unet_argmax2(hip.ptr(tie), 32, 16, 4, hip.ptr(am2), 1, 4, 4, hip.stream()))
     assert int(am2.sum()) == 0                                               # ties -> class 0
     # L3 SGD momentum, two steps, against torch.optim.SGD
+    torch.manual_seed(0)
     ps = [torch.randn(n, device="cuda") for n in (5000, 3, 70001)]
     ref = [torch.nn.Parameter(p.clone()) for p in ps]
     opt = torch.optim.SGD(ref, lr=1e-4, momentum=0.99)
@@ -261,4 +262,4 @@ def test_step_side_kernels(hip, golden_dir):
         opt.step()
         hip.check(L.unet_sgd_momentum(hip.ptr_table(ps), hip.ptr_table(gs), hip.ptr_table(bufs), numel, 3, 1e-4, 0.99, int(step == 0), hip.stream()))
     for p, r in zip(ps, ref):
-        assert torch.allclose(p, r.detach(), rtol=0, atol=1e-7)
+        assert torch.allclose(p, r.detach(), rtol=0, atol=5e-7)      # <= 1 ulp at |p| ~ 4 (fma vs mul+add)
