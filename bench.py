@@ -150,9 +150,13 @@ def main():
                 fam[name] = (ms.value, n.value, fl.value)
             ms0, n0, fl0 = fam["igemm_f32"]
             ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # from tools/summarize_profiles.py (rocprofv3 --pmc passes)
+            if os.path.exists(tpath) and B == B_PER_GPU:
+                traffic = json.load(open(tpath))["igemm_hbm_mb_per_launch"] * 1e6
             out["roofline"] = {"bound": "mfma", "kernel": "igemm_f32_kernel (conv fwd / dgrad / up-conv implicit GEMM)",
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                                "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
                                "gflop_per_launch": fl0 / max(n0, 1) / 1e9,
                                "share_of_step_time": ms0 / (dt * 1e3)}

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_*: run locally after gpurun."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+json.dump(bench, open("profiles/%s_bench.json" % tag, "w"), indent=1)
+shutil.copy(glob.glob(os.path.join(src, "stats/*/*kernel_stats.csv"))[0], "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
+shutil.copy(os.path.join(src, "launches.csv"), "profiles/%s_launches.csv" % tag)
+
+def short(n):
+    return n.split("(")[0].replace("void ", "").replace("unet::", "")[:44]
+
+stats = list(csv.DictReader(open("profiles/%s_rocprofv3_kernel_stats.csv" % tag)))
+ig = [r for r in stats if "igemm_f32_kernel" in r["Name"]]
+ig_calls = sum(int(r["Calls"]) for r in ig); ig_ns = sum(float(r["TotalDurationNs"]) for r in ig)
+
+def counters(sub):
+    d = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
+    f = glob.glob(os.path.join(src, sub, "*/*counter_collection.csv"))[0]
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"]); d[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen:
+            seen.add((k, r["Dispatch_Id"])); n[k] += 1
+    dur = collections.defaultdict(float)
+    f = glob.glob(os.path.join(src, sub, "*/*kernel_trace.csv"))[0]
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return d, n, dur
+
+sq, nsq, dur = counters("sq"); fe, nfe, _ = counters("fetch"); wr, nwr, _ = counters("write"); ld, nld, _ = counters("lds")
+lines = ["# %s — rocprofv3 PMC summary (bench.py --steps 2 --warmup 1, separate --pmc passes)" % tag, "",
+         "FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM); units MB.",
+         "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock); clock = GRBM_GUI_ACTIVE / 8 / duration.", "",
+         "| kernel | launches | ms total | clock GHz | MFMA busy | WAIT_ANY/WAVE | fetch MB/launch (x2) | write MB/launch | LDS bank-conflict cycles / LDS active |",
+         "|---|---|---|---|---|---|---|---|---|"]
+tot_f = tot_w = tot_n = 0
+for k in sorted(dur, key=lambda k: -dur[k])[:14]:
+    c = sq[k]; clk = c["GRBM_GUI_ACTIVE"] / 8 / dur[k] if dur[k] else 0
+    busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * dur[k] * clk) if clk else 0
+    f = 2 * fe[k]["FETCH_SIZE"] / 1024 / max(nfe[k], 1); w = wr[k]["WRITE_SIZE"] / 1024 / max(nwr[k], 1)
+    lb = ld[k]["SQ_LDS_BANK_CONFLICT"] / max(ld[k]["SQ_ACTIVE_INST_LDS"], 1)
+    lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.3f |" % (k, nsq[k], dur[k] / 1e6, clk, busy,
+                 c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), f, w, lb))
+    if "igemm_f32_kernel" in k:
+        tot_f += 2 * fe[k]["FETCH_SIZE"] / 1024; tot_w += wr[k]["WRITE_SIZE"] / 1024; tot_n += nfe[k]
+traffic = (tot_f + tot_w) / max(tot_n, 1)
+lines += ["", "igemm_f32_kernel (all instantiations): HBM traffic %.1f MB per launch (fetch %.1f + write %.1f), %d launches." %
+          (traffic, tot_f / tot_n, tot_w / tot_n, tot_n),
+          "rocprofv3 --stats (bench.py --steps 5 --warmup 2): igemm avg launch %.4f ms over %d calls; bench.py HIP events: %.4f ms." %
+          (ig_ns / ig_calls / 1e6, ig_calls, bench["roofline"]["avg_launch_ms"])]
+open("profiles/%s_pmc_summary.md" % tag, "w").write("\n".join(lines) + "\n")
+json.dump({"igemm_hbm_mb_per_launch": traffic, "source": "profiles/%s_pmc_summary.md" % tag}, open("profiles/pmc_traffic.json", "w"))
+print("\n".join(lines[-3:]))
