@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="tiles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for one rank")
     ap.add_argument("--dump-launches", default=None, help="write per-launch timings (CSV) of the timed region here")
     args = ap.parse_args()
 
@@ -75,8 +76,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import _hip
@@ -86,7 +90,7 @@ def main():
 
     torch.manual_seed(0)                                   # same initial weights on every rank
     net = network.Unet().to(dev)
-    if world > 1:
+    if use_dist:
         net.enable_data_parallel()
     opt = hip_optim.SGD(net.parameters(), lr=1e-4, momentum=0.99)
 
@@ -105,7 +109,7 @@ def main():
         return hip_optim.argmax2(logits.detach()), loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,7 +128,7 @@ def main():
         L.unet_profile_enable(0)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
@@ -168,7 +172,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

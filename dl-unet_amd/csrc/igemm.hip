@@ -28,17 +28,25 @@ int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-// ---- epilogue: per-row destination offsets through
-// LDS, then bias / add / ReLU / mask / store.  Rows past M get row M-1's (valid) offset so every
-// mask/add load is issued unconditionally and back to back; only the store is predicated.
+// ---- epilogue: bias / add / ReLU / mask / store with 16-byte accesses.
+// The MFMA accumulator layout gives a lane one column and 16 rows, i.e. dword stores (64 per lane; measured
+// ~4 us of store issue per workgroup, 18 % of a short-K layer).  Each wave therefore transposes its 32x32
+// sub-tiles through a private 4.5 KiB LDS patch (row pitch 36 floats: 16-B aligned, conflict-free) and
+// writes/reads global memory as float4: 16 stores per lane, each wave instruction covering 8 rows x 128 B.
+// Rows past M use row M-1's (valid) offset so mask/add loads are unconditional; only the store is predicated.
+constexpr int EPI_PITCH = 36;
+constexpr int EPI_WAVE_BYTES = 32 * EPI_PITCH * 4;
+
 template <int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid,
-                                               unsigned *rowoff /* LDS, BM entries */)
+                                               unsigned char *lds /* >= BM*4 + 4*EPI_WAVE_BYTES bytes, free */)
 {
     constexpr int WN = BN / 64;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
+    unsigned *rowoff = (unsigned *)lds;
+    float *patch = (float *)(lds + BM * 4 + wave * EPI_WAVE_BYTES);
     if (tid < BM) {
         int m = m0 + tid;
         m = m < p.M ? m : p.M - 1;
@@ -56,54 +64,63 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2]
         rowoff[tid] = off;
     }
     __syncthreads();
+    const int rrow = lane >> 3, cg = lane & 7;           // read-back role: row rrow + 8k, columns 4cg..4cg+3
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        const int n_raw = n0 + wn * 64 + tn * 32 + l31;
-        const bool n_ok = n_raw < p.Nn;
-        const int n = n_ok ? n_raw : p.Nn - 1;
-        int coloff, bidx;
-        if (!p.scatter) {
-            coloff = p.dn0 + n;
-            bidx = p.cout ? n % p.cout : n;
-        } else {
-            const int ab = n / p.cout;
-            bidx = n - ab * p.cout;
-            coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + bidx;
+        const int nb = n0 + wn * 64 + tn * 32;
+        float bv = 0.f;
+        if (p.bias) {
+            int n = nb + l31;
+            n = n < p.Nn ? n : p.Nn - 1;
+            bv = p.bias[p.cout ? n % p.cout : n];
         }
-        const float bv = p.bias ? p.bias[bidx] : 0.f;
+        const int n4 = nb + 4 * cg;
+        const bool n_ok = n4 < p.Nn;
+        const int nc = n_ok ? n4 : 0;
+        int coloff;
+        if (!p.scatter) {
+            coloff = p.dn0 + nc;
+        } else {
+            const int ab = nc / p.cout;
+            coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + (nc - ab * p.cout);
+        }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
-            size_t o[16];
-            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                o[r] = (size_t)rowoff[row] + (size_t)coloff;
-                v[r] = acc[tm][tn][r] + bv;
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_PITCH + l31] = acc[tm][tn][r] + bv;
+            f32x4 v[4];
+            size_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = *(const f32x4 *)(patch + (rrow + 8 * k) * EPI_PITCH + 4 * cg);
+                o[k] = (size_t)rowoff[wm * 64 + tm * 32 + rrow + 8 * k] + (size_t)coloff;
             }
             if (p.add) {
-                float t[16];
+                f32x4 t[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = p.add[o[r]];
+                for (int k = 0; k < 4; ++k) t[k] = *(const f32x4 *)(p.add + o[k]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += t[r];
+                for (int k = 0; k < 4; ++k) v[k] += t[k];
             }
             if (p.relu) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[k][c] = v[k][c] > 0.f ? v[k][c] : 0.f;
             }
             if (p.mask) {
-                float t[16];
+                f32x4 t[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = p.mask[o[r]];
+                for (int k = 0; k < 4; ++k) t[k] = *(const f32x4 *)(p.mask + o[k]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[k][c] = t[k][c] > 0.f ? v[k][c] : 0.f;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m0 + row < p.M) p.dst[o[r]] = v[r];
-            }
+            for (int k = 0; k < 4; ++k)
+                if (n_ok && m0 + wm * 64 + tm * 32 + rrow + 8 * k < p.M) *(f32x4 *)(p.dst + o[k]) = v[k];
         }
     }
 }
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
         __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
     }
 
-    igemm_epilogue<BM, BN>(p, acc, m0, n0, tid, (unsigned *)smem);
+    igemm_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
 }
 
 // Algorithmic FLOPs of one launch: 2 * (in-bounds (pixel, tap) pairs) * channels * N.  Taps that fall
@@ -307,6 +324,7 @@ int launch_igemm(IgemmP p, hipStream_t st)
     ARG_CHECK(kd == p.Kd, "igemm: Kd %d does not match sources (%d)", p.Kd, kd);
     ARG_CHECK(p.M == p.NB * p.OH * p.OW && p.M > 0 && p.Nn > 0, "igemm: bad M/N");
     if (!p.scatter) ARG_CHECK(p.DH == p.OH && p.DW == p.OW, "igemm: linear store needs dst extent == output domain");
+    ARG_CHECK(p.DC % 4 == 0 && p.dn0 % 4 == 0 && p.Nn % 4 == 0 && (!p.scatter || p.cout % 4 == 0), "igemm: 16-byte stores need channel counts that are multiples of 4");
     ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0xFFFFFFFFull, "igemm: destination exceeds 32-bit element offsets");
     for (int i = 0; i < p.nsrc; ++i)
         ARG_CHECK((size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C < 0x7FFFFFFFull, "igemm: source exceeds 31-bit element offsets");

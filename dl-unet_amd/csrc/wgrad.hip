@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
         }
     }
 
-    // partial tile -> slab[P][t][Ci][Cj] (+ [Cj] bias partials behind it)
+    // partial tile -> slab of partition P (+ [Cj] bias partials behind the T*Ci*Cj weight partials)
     float *slab = p.slab + (size_t)P * k.pstride;
     if (do_bias) {
         float *red = (float *)smem;             // all LDS reads of the loop are behind its last barrier
@@ -161,18 +161,17 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
         __syncthreads();
         if (tid < 64) slab[(size_t)T * p.Ci * p.Cj + jt * 64 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
     }
+    // register-order layout [tile][wave][t][r/4][lane][r%4]: one 16-byte store per lane and (t, r/4), 1 KiB per
+    // wave instruction (the 144 dword stores this replaces were store-issue bound); the reduce kernel decodes it.
+    f32x4 *dst4 = (f32x4 *)(slab + ((size_t)(tile * 4 + wave) * T) * 1024) + lane;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = it * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int j = jt * 64 + wj * 32 + l31;
-            slab[((size_t)t * p.Ci + i) * p.Cj + j] = acc[t][r];
-        }
-    }
+        for (int rq = 0; rq < 4; ++rq)
+            dst4[(t * 4 + rq) * 64] = f32x4{acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]};
 }
 
-// out[i*si + j*sj + t*st] = sum_P slab[P][t][i][j]  and  db[j] = sum_P slab[P][T*Ci*Cj + j], in a fixed order.
+// out[i*si + j*sj + t*st] = sum_P slab_P(t,i,j)  and  db[j] = sum_P slab[P][T*Ci*Cj + j], in a fixed order.
 // Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
 // even when the output is tiny (64x64x9) and the partition count is in the thousands.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, size_t pstride, int T, int Ci, int Cj,
@@ -201,10 +200,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         if (grp == 0 && e < total) {
             const float v = (red[lane_e] + red[lane_e + 64]) + (red[lane_e + 128] + red[lane_e + 192]);
             if (e < nw) {
-                const int j = (int)(e % Cj);
-                const size_t ti = e / Cj;
-                const int i = (int)(ti % Ci);
-                const int t = (int)(ti / Ci);
+                // decode the register-order slab index (see wgrad_f32_kernel): [tile][wave][t][r/4][lane][r%4]
+                const int ri = (int)(e & 3), ln = (int)((e >> 2) & 63), rq = (int)((e >> 8) & 3);
+                const size_t hi = e >> 10;
+                const int t = (int)(hi % T);
+                const int wv = (int)((hi / T) & 3);
+                const int tile = (int)(hi / T / 4);
+                const int ntj = Cj >> 6;
+                const int it = tile / ntj, jt = tile - it * ntj;
+                const int i = it * 64 + (wv >> 1) * 32 + ri + 8 * rq + 4 * (ln >> 5);
+                const int j = jt * 64 + (wv & 1) * 32 + (ln & 31);
                 out[i * si + j * sj + t * st] = v;
             } else {
                 db[e - nw] = v;

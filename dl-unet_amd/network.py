@@ -107,7 +107,7 @@ class _UnetFunction(torch.autograd.Function):
         for s in range(buckets.n_stages()):
             _hip.check(L.unet_backward_stage(h.h, s, ptab, _hip.ptr(dlogits), gtab, _hip.ptr(ctx.ws), ctx.nbytes,
                                              _hip.stream()), "unet_backward_stage %d" % s)
-            if dp is not None and dp[1] > 1:
+            if dp is not None:
                 # RCCL all-reduce of this bucket on the communicator's stream, overlapping the next stage
                 works.append(buckets.reduce_stage(flat, s, dp[0]))
         for w in works:
