@@ -51,14 +51,17 @@ struct GSrc {
 struct IgemmP {
     GSrc src[2];
     int nsrc;
-    const float *wt;  // packed weights [Nn][Kd]
-    int Kd;
+    const float *wt;  // packed weights [Nn][ldw], this launch contracts over columns [0, Kd)
+    int Kd, ldw;
     int T, TX;        // taps, taps per row
     int stride, oy0, ox0;
     int NB, OH, OW, M, Nn;
     float *dst;
     int DH, DW, DC, dn0;
-    int scatter;      // 0: dst pixel == m (DH==OH, DW==OW); 1: up-conv scatter n -> (a,b,co)
+    int scatter;      // 0: dst pixel == m (DH==OH, DW==OW); 1: up-conv scatter n -> (a,b,co);
+                      // 2: window: dst pixel = (oy + dwy0, ox + dwx0) of a DH x DW tensor
+    int dwy0, dwx0;
+    int rw0, rw1;     // if rw1 > rw0: ReLU is applied only OUTSIDE the output window [rw0,rw1)^2 (a later launch finishes it)
     int cout;         // scatter: channels per (a,b) group; also bias index = n % cout
     const float *bias;
     int relu;

@@ -39,7 +39,7 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_PITCH * 4;
 
 template <int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid,
-                                               unsigned char *lds /* >= BM*4 + 4*EPI_WAVE_BYTES bytes, free */)
+                                               unsigned char *lds /* >= BM*5 + 4*EPI_WAVE_BYTES bytes, free */)
 {
     constexpr int WN = BN / 64;
     const int lane = tid & 63, wave = tid >> 6;
@@ -47,11 +47,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2]
     const int l31 = lane & 31, lh = lane >> 5;
     unsigned *rowoff = (unsigned *)lds;
     float *patch = (float *)(lds + BM * 4 + wave * EPI_WAVE_BYTES);
+    unsigned char *inwin = lds + BM * 4 + 4 * EPI_WAVE_BYTES;     // per-row flag: pixel inside the deferred-ReLU window
+    const bool relu_win = p.rw1 > p.rw0;
     if (tid < BM) {
         int m = m0 + tid;
         m = m < p.M ? m : p.M - 1;
         unsigned off;
-        if (!p.scatter) {
+        unsigned char flag = 0;
+        if (!p.scatter && !relu_win) {
             off = (unsigned)m * (unsigned)p.DC;
         } else {
             const int ohw = p.OH * p.OW;
@@ -59,9 +62,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2]
             const int rem = m - img * ohw;
             const int oy = rem / p.OW;
             const int ox = rem - oy * p.OW;
-            off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
+            if (p.scatter == 1) off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
+            else if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
+            else off = (unsigned)m * (unsigned)p.DC;
+            flag = relu_win && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
         }
         rowoff[tid] = off;
+        inwin[tid] = flag;
     }
     __syncthreads();
     const int rrow = lane >> 3, cg = lane & 7;           // read-back role: row rrow + 8k, columns 4cg..4cg+3
@@ -78,7 +85,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2]
         const bool n_ok = n4 < p.Nn;
         const int nc = n_ok ? n4 : 0;
         int coloff;
-        if (!p.scatter) {
+        if (p.scatter != 1) {
             coloff = p.dn0 + nc;
         } else {
             const int ab = nc / p.cout;
@@ -105,9 +112,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2]
             }
             if (p.relu) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k) {
+                    const bool defer = relu_win && inwin[wm * 64 + tm * 32 + rrow + 8 * k];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[k][c] = v[k][c] > 0.f ? v[k][c] : 0.f;
+                    for (int c = 0; c < 4; ++c) v[k][c] = (v[k][c] > 0.f || defer) ? v[k][c] : 0.f;
+                }
             }
             if (p.mask) {
                 f32x4 t[4];
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
     for (int j = 0; j < RB; ++j) {
         int n = n0 + srow + 32 * j;
         n = n < p.Nn ? n : p.Nn - 1;
-        b_off[j] = n * p.Kd + coff;
+        b_off[j] = n * p.ldw + coff;
     }
 
     int s = 0, ty = 0, tx = 0, kc = 0, kglob = 0;
@@ -324,6 +333,9 @@ int launch_igemm(IgemmP p, hipStream_t st)
     ARG_CHECK(kd == p.Kd, "igemm: Kd %d does not match sources (%d)", p.Kd, kd);
     ARG_CHECK(p.M == p.NB * p.OH * p.OW && p.M > 0 && p.Nn > 0, "igemm: bad M/N");
     if (!p.scatter) ARG_CHECK(p.DH == p.OH && p.DW == p.OW, "igemm: linear store needs dst extent == output domain");
+    if (p.scatter == 2) ARG_CHECK(p.dwy0 >= 0 && p.dwx0 >= 0 && p.OH + p.dwy0 <= p.DH && p.OW + p.dwx0 <= p.DW, "igemm: window store outside dst");
+    if (p.ldw == 0) p.ldw = p.Kd;
+    ARG_CHECK(p.ldw >= p.Kd && p.ldw % 4 == 0, "igemm: bad weight pitch");
     ARG_CHECK(p.DC % 4 == 0 && p.dn0 % 4 == 0 && p.Nn % 4 == 0 && (!p.scatter || p.cout % 4 == 0), "igemm: 16-byte stores need channel counts that are multiples of 4");
     ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0xFFFFFFFFull, "igemm: destination exceeds 32-bit element offsets");
     for (int i = 0; i < p.nsrc; ++i)
@@ -331,7 +343,7 @@ int launch_igemm(IgemmP p, hipStream_t st)
     p.zeros = zero_page();
     if (!p.zeros) return -2;
     static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();
-    if (gen == 2) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
+    if (gen == 2 && p.scatter != 2 && p.rw1 <= p.rw0) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
     if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true>(p, st) : launch_cfg<128, 128, false>(p, st);
     return pad ? launch_cfg<256, 64, true>(p, st) : launch_cfg<256, 64, false>(p, st);
 }

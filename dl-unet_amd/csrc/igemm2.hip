@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm2_f32_kernel(co
     for (int j = 0; j < RB; ++j) {
         int n = n0 + srow + 64 * j;
         n = n < p.Nn ? n : p.Nn - 1;
-        b_off[j] = n * p.Kd + coff;
+        b_off[j] = n * p.ldw + coff;
     }
     int s_src = 0, ty = 0, tx = 0, kc = 0, kglob = 0;
     const float *sp = nullptr;

@@ -146,6 +146,36 @@ static IgemmP conv_fwd_desc(const float *x1, int H1, int W1, int C1, int pad1, c
     return p;
 }
 
+// Forward 3x3 conv over the virtual concat.  When the skip source is zero-padded (pad > 0) its taps only
+// reach the output window [pad-2, pad+H1): running it as part of one GEMM would spend 30-50 % of that
+// layer's MFMA work on zeros.  So: launch 1 = up-conv source over the full domain (+bias, ReLU outside the
+// window), launch 2 = skip source over the window only, accumulating in place (+ReLU).  Same math, same
+// K order per source; the two partial sums are added in fp32.
+static int conv_fwd_launch(const float *x1, int H1, int C1, int pad1, const float *x2, int C2, int B, int H,
+                           const float *wt, const float *bias, int K, int relu, float *y, hipStream_t st)
+{
+    const int Ho = H - 2;
+    int w0 = pad1 - 2; if (w0 < 0) w0 = 0;
+    int w1 = pad1 + H1; if (w1 > Ho) w1 = Ho;
+    const bool split = x2 && pad1 > 0 && (double)(w1 - w0) * (w1 - w0) < 0.85 * (double)Ho * Ho;
+    if (!split) {
+        IgemmP p = conv_fwd_desc(x1, H1, H1, C1, pad1, x2, x2 ? C2 : 0, B, H, H, wt, bias, K, relu, y);
+        return launch_igemm(p, st);
+    }
+    const int ldw = 9 * (C1 + C2);
+    IgemmP a = conv_fwd_desc(x2, H, H, C2, 0, nullptr, 0, B, H, H, wt + 9 * C1, bias, K, relu, y);
+    a.ldw = ldw;
+    if (relu) { a.rw0 = w0; a.rw1 = w1; }
+    int rc = launch_igemm(a, st);
+    if (rc) return rc;
+    IgemmP b = conv_fwd_desc(x1, H1, H1, C1, pad1, nullptr, 0, B, H, H, wt, nullptr, K, relu, y);
+    b.ldw = ldw;
+    b.OH = b.OW = w1 - w0; b.M = B * b.OH * b.OW; b.oy0 = b.ox0 = w0;
+    b.scatter = 2; b.dwy0 = b.dwx0 = w0; b.DH = b.DW = Ho;
+    b.add = y;
+    return launch_igemm(b, st);
+}
+
 // dgrad of a 3x3 valid conv: dx over the window [oy0, oy0+OHW) of the conv's (virtual) input
 static IgemmP conv_dgrad_desc(const float *dz, int Ho, int Wo, int K, int B, int OHW, int o0,
                               const float *wt_rows, int Nn, float *dx, const float *mask, const float *add)
@@ -386,9 +416,8 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
         u.dst = WS(pl.u[l]); u.DH = pl.eu[l]; u.DW = pl.eu[l]; u.DC = ch[l]; u.scatter = 1; u.cout = ch[l];
         u.bias = PARAM(2 * UP_L[l] + 1);
         if ((rc = launch_igemm(u, st))) return rc;
-        IgemmP c1 = conv_fwd_desc(WS(pl.t[l]), pl.et[l], pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l], pl.eu[l],
-                                  WS(pl.wt_fwd[C1E_L[l]]), PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]));
-        if ((rc = launch_igemm(c1, st))) return rc;
+        if ((rc = conv_fwd_launch(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l],
+                                  WS(pl.wt_fwd[C1E_L[l]]), PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st))) return rc;
         IgemmP c2 = conv_fwd_desc(WS(pl.d1[l]), pl.ed1[l], pl.ed1[l], ch[l], 0, nullptr, 0, B, pl.ed1[l], pl.ed1[l],
                                   WS(pl.wt_fwd[C2E_L[l]]), PARAM(2 * C2E_L[l] + 1), ch[l], 1, WS(pl.d2[l]));
         if ((rc = launch_igemm(c2, st))) return rc;
@@ -604,9 +633,9 @@ int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
     hipStream_t st = (hipStream_t)stream;
     int rc = pack_conv_fwd((const float *)w_oihw, (float *)scratch, K, C1, x2 ? C2 : 0, st);
     if (rc) return rc;
-    IgemmP p = conv_fwd_desc((const float *)x1, H1, W1, C1, pad1, (const float *)x2, x2 ? C2 : 0, B, H, W,
-                             (const float *)scratch, (const float *)bias, K, relu, (float *)y);
-    return launch_igemm(p, st);
+    ARG_CHECK(H == W && H1 == W1, "conv3x3_fwd: square tiles only");
+    return conv_fwd_launch((const float *)x1, H1, C1, pad1, (const float *)x2, x2 ? C2 : 0, B, H, (const float *)scratch,
+                           (const float *)bias, K, relu, (float *)y, st);
 }
 
 size_t unet_conv3x3_bwd_scratch_bytes(int B, int H, int W, int C, int K)
