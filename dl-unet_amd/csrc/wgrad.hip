@@ -14,7 +14,10 @@
 // wave accumulates T 32x32 MFMA tiles (v_mfma_f32_32x32x2_f32, K = a pair of pixels).  Partial tiles
 // go to a slab and a second kernel reduces them in a fixed order (deterministic, no atomics).
 #include "common.hpp"
+#include <array>
 #include <cstdio>
+#include <map>
+#include <mutex>
 
 namespace unet {
 
@@ -27,6 +30,7 @@ constexpr int PWMAX = 32;     // pixels per strip (MFMA K = pixel pairs)
 struct WgradK {               // kernel-side copy with the derived decomposition
     WgradP p;
     int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
+    int nparts, ngroups;               // pixel partitions, and workgroups per channel tile that share them
     size_t pstride;                    // floats per partition in the slab: T*Ci*Cj weights + Cj bias partials
 };
 
@@ -57,29 +61,46 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
 
-    // block -> (pixel partition P, channel tile); tiles of one partition are neighbours on one XCD
+    // block -> (partition group grp, channel tile); tiles of one group are neighbours on one XCD.  A workgroup
+    // accumulates ALL partitions P = grp, grp+ngroups, ... of its tile in registers and writes one slab, so the
+    // slab traffic is set by the number of resident workgroups, not by how finely the pixels are partitioned.
     int logical;
     {
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
     const int ntile = k.ntile_i * k.ntile_j;
-    const int P = logical / ntile;
-    const int tile = logical - P * ntile;
+    const int grp = logical / ntile;
+    const int tile = logical - grp * ntile;
     const int it = tile / k.ntile_j, jt = tile - it * k.ntile_j;
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    const float *zsrc = p.zeros + 4 * l15;
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // fused bias gradient: the i-tile-0 workgroups also sum their Y strip over pixels (db[j] = sum dz)
+    const bool do_bias = p.db != nullptr && it == 0;
+    float bsum = 0.f;
+    const int bch = tid & 63, bpg = tid >> 6;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_lane = (wi * 32 + l31) * 4;      // byte offset of this lane's X channel within a pixel
+    const int b_lane = (wj * 32 + l31) * 4;
+
+    for (int P = grp; P < k.nparts; P += k.ngroups) {
     const int strip = P % k.nstrips;
     const int pc = P / k.nstrips;
     const int chunk = pc % k.nchunks;
     const int img = pc / k.nchunks;
-
     const int x0 = p.xwin0 + strip * k.pw;
     int pwv = p.xwin1 - x0; pwv = pwv < k.pw ? pwv : k.pw;           // valid pixels in this strip
     const int ya = p.ywin0 + chunk * k.rows_per_chunk;
     int yb = ya + k.rows_per_chunk; yb = yb < p.ywin1 ? yb : p.ywin1;
     const int npairs = (pwv + 1) >> 1;
-
-    const int l15 = lane & 15, lq = lane >> 4;
-    const float *zsrc = p.zeros + 4 * l15;
     const int xcol0 = (x0 + p.ox0) * S - p.xpad;
 
     // stage one X row (global row xr of image img) into its ring slot, pixel group g
@@ -110,20 +131,6 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
         }
     };
 
-    f32x16 acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // fused bias gradient: the i-tile-0 workgroups also sum their Y strip over pixels (db[j] = sum dz)
-    const bool do_bias = p.db != nullptr && it == 0;
-    float bsum = 0.f;
-    const int bch = tid & 63, bpg = tid >> 6;
-
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int a_lane = (wi * 32 + l31) * 4;      // byte offset of this lane's X channel within a pixel
-    const int b_lane = (wj * 32 + l31) * 4;
-
     if (ya < yb) {
         stage_step(ya, 0, 0, TY);                // prologue: all TY rows + Y row
         __syncthreads();
@@ -153,8 +160,10 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
         }
     }
 
-    // partial tile -> slab of partition P (+ [Cj] bias partials behind the T*Ci*Cj weight partials)
-    float *slab = p.slab + (size_t)P * k.pstride;
+    }   // partitions of this workgroup
+
+    // accumulated tile -> slab of this group (+ [Cj] bias partials behind the T*Ci*Cj weight partials)
+    float *slab = p.slab + (size_t)grp * k.pstride;
     if (do_bias) {
         float *red = (float *)smem;             // all LDS reads of the loop are behind its last barrier
         red[tid] = bsum;
@@ -229,30 +238,57 @@ static void decompose(const WgradP &p, WgradK &k)
     k.nstrips = cdiv(wx, pw);
     k.ntile_i = p.Ci / 64;
     k.ntile_j = p.Cj / 64;
-    // Row-chunking: every workgroup takes the same time, so pick the chunk count whose total workgroup
-    // count fills whole rounds of the resident slots (256 CUs x 3 workgroups for the 3x3 kernel), with
-    // a mild preference for fewer partitions (each one costs a slab write + read in the reduce) and at
-    // least 8 rows per workgroup to amortise that write.
-    const long base = (long)p.NB * k.nstrips * k.ntile_i * k.ntile_j;
+    // Partitioning.  The pixels are cut into partitions (image x row-chunk x strip); `ngroups` workgroups per
+    // channel tile share them round-robin, each accumulating its partitions in registers and writing ONE slab.
+    // Choose rows-per-chunk r and ngroups to minimise  rounds(ngroups*ntile / resident slots) x ceil(nparts/ngroups) x r
+    // (all workgroups of a launch do the same per-row work), preferring fewer groups (slab traffic) on ties.
+    const int ntile = k.ntile_i * k.ntile_j;
     const int slots = 256 * (p.TY == 3 ? 3 : 2);
-    int best_n = 1;
-    double best_score = -1e30;
-    const int max_chunks = wy >= 8 ? wy / 8 : 1;
-    for (int n = 1; n <= max_chunks; ++n) {
-        const int rows_n = cdiv(wy, n);
-        const int n_eff = cdiv(wy, rows_n);
-        if (n_eff != n) continue;                                 // same decomposition as a smaller n
-        const long nblk = base * n;
-        const long rounds = (nblk + slots - 1) / slots;
-        // the last chunk may be short: count work in rows, not workgroups
-        const double eff = (double)base * wy / ((double)rounds * slots * rows_n);
-        const double score = eff - 0.015 * (double)rounds;
-        if (score > best_score) { best_score = score; best_n = n; }
-        if (nblk > 8L * slots) break;
+    const long per_chunk = (long)p.NB * k.nstrips;
+    // the search is a few million cheap iterations: memoise per shape (hot calls hit the cache)
+    static std::mutex mu;
+    static std::map<std::array<long, 4>, std::pair<int, int>> cache;
+    const std::array<long, 4> key = {per_chunk, (long)wy, (long)ntile, (long)slots};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto itc = cache.find(key);
+        if (itc != cache.end()) {
+            k.rows_per_chunk = itc->second.first;
+            k.nchunks = cdiv(wy, k.rows_per_chunk);
+            k.nparts = (int)(per_chunk * k.nchunks);
+            k.ngroups = itc->second.second;
+            k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + p.Cj, 64);
+            return;
+        }
     }
-    int rows = cdiv(wy, best_n);
-    k.rows_per_chunk = rows;
-    k.nchunks = cdiv(wy, rows);
+    double best = 1e300;
+    int best_r = wy, best_g = 1;
+    for (int r = 4; r <= wy; ++r) {
+        const int nch = cdiv(wy, r);
+        if (r > 4 && cdiv(wy, r - 1) == nch && r != wy) continue;   // a smaller r gives the same chunk count: skip (keep the first)
+        const long nparts = per_chunk * nch;
+        long gmax = nparts < 8L * slots / ntile + 1 ? nparts : 8L * slots / ntile + 1;
+        if (gmax < 1) gmax = 1;
+        for (long g = 1; g <= gmax; ++g) {
+            // workgroups beyond the resident slots queue; measured behaviour sits between lockstep rounds
+            // (ceil) and perfect refill (fraction), so blend the two; per-partition fixed cost ~ 2 rows' worth
+            // (prologue staging of the halo ring, pipeline warm-up)
+            const double frac = (double)(g * ntile) / (double)slots;
+            const double rounds = frac <= 1.0 ? 1.0 : 0.5 * (frac + (double)((g * ntile + slots - 1) / slots));
+            const double t = rounds * (double)((nparts + g - 1) / g) * (double)(r + 2);
+            const double score = t * (1.0 + 0.02 * rounds);            // fewer groups on ties: less slab traffic
+            if (score < best - 1e-9) { best = score; best_r = r; best_g = (int)g; }
+        }
+        if (nch == 1) break;
+    }
+    k.rows_per_chunk = best_r;
+    k.nchunks = cdiv(wy, best_r);
+    k.nparts = (int)(per_chunk * k.nchunks);
+    k.ngroups = best_g;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        cache[key] = std::make_pair(best_r, best_g);
+    }
     k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + p.Cj, 64);
 }
 
@@ -260,7 +296,7 @@ size_t wgrad_slab_need(const WgradP &p)
 {
     WgradK k{};
     decompose(p, k);
-    return (size_t)p.NB * k.nchunks * k.nstrips * k.pstride * sizeof(float);
+    return (size_t)k.ngroups * k.pstride * sizeof(float);
 }
 
 static double wgrad_alg_flops(const WgradP &p)
@@ -274,7 +310,7 @@ static double wgrad_alg_flops(const WgradP &p)
 }
 
 template <int TY, int TX, int S>
-static int launch_wgrad_t(const WgradK &k, int nP, hipStream_t st)
+static int launch_wgrad_t(const WgradK &k, hipStream_t st)
 {
     using G = WgradGeom<TY, TX, S>;
     static bool attr_done = false;
@@ -284,10 +320,10 @@ static int launch_wgrad_t(const WgradK &k, int nP, hipStream_t st)
         attr_done = true;
     }
     char tag[96];
-    snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d> Ci=%d Cj=%d Y=%dx%d win=%d nP=%d pw=%d rows=%d", TY, TX, S, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
-             k.p.ywin1 - k.p.ywin0, nP, k.pw, k.rows_per_chunk);
+    snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
+             k.p.ywin1 - k.p.ywin0, k.nparts, k.pw, k.rows_per_chunk, k.ngroups);
     prof_begin(1, wgrad_alg_flops(k.p), st, tag);
-    hipLaunchKernelGGL(kern, dim3(nP * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
+    hipLaunchKernelGGL(kern, dim3(k.ngroups * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -304,13 +340,13 @@ int launch_wgrad(WgradP p, hipStream_t st)
     WgradK k{};
     k.p = p;
     decompose(p, k);
-    const int nP = p.NB * k.nchunks * k.nstrips;
+    const int nP = k.ngroups;                 // slabs to reduce
     const int T = p.TY * p.TX;
     const size_t need = (size_t)nP * k.pstride * sizeof(float);
     ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
     int rc;
-    if (p.TY == 3 && p.TX == 3 && p.stride == 1) rc = launch_wgrad_t<3, 3, 1>(k, nP, st);
-    else if (p.TY == 2 && p.TX == 2 && p.stride == 2) rc = launch_wgrad_t<2, 2, 2>(k, nP, st);
+    if (p.TY == 3 && p.TX == 3 && p.stride == 1) rc = launch_wgrad_t<3, 3, 1>(k, st);
+    else if (p.TY == 2 && p.TX == 2 && p.stride == 2) rc = launch_wgrad_t<2, 2, 2>(k, st);
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
     if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");
