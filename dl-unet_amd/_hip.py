@@ -41,6 +41,12 @@ _SIGS = {
     "unet_onehot2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "unet_argmax2": (C.c_int, [vp, C.c_long, C.c_long, C.c_long, vp, C.c_int, C.c_int, C.c_int, vp]),
     "unet_sgd_momentum": (C.c_int, [vp, vp, vp, C.POINTER(C.c_size_t), C.c_int, C.c_float, C.c_float, C.c_int, vp]),
+    "unet_minmax": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp]),
+    "unet_mirror_pad": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "unet_eval_masks": (C.c_int, [vp, C.c_long, C.c_long, C.c_long, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "unet_class_balance": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "unet_gaussian_filter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp]),
+    "unet_warp_bilinear": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "unet_conv3x3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "unet_conv3x3_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    vp, vp, C.c_int, C.c_int, vp, vp, vp]),

@@ -16,7 +16,21 @@ def weighted_map(gt_batch):
 
 def class_balance(gt_batch):
     """Per-image class-frequency weight map (functions.py:82-117): every pixel of value v gets
-    count(second unique value) / count(v).  gt_batch: [B,H,W] -> float [B,H,W] on the CPU."""
+    count(second unique value) / count(v).  gt_batch: [B,H,W] -> float [B,H,W].
+    Host tensors take the reference's CPU algorithm; {0,1} int64 labels already on the HIP device
+    use unet_class_balance (two counting reductions and a select, no host round trip)."""
+    if gt_batch.is_cuda:
+        import _hip
+        gt = gt_batch.contiguous()
+        if gt.dtype != torch.int64:
+            gt = gt.long()
+        B, H, W = gt.shape
+        w = torch.empty(B, H, W, dtype=torch.float32, device=gt.device)
+        counts = torch.empty(B, dtype=torch.int64, device=gt.device)
+        _hip.check(_hip.lib().unet_class_balance(_hip.ptr(gt), B, H, W, _hip.ptr(w), _hip.ptr(counts), _hip.stream()), "unet_class_balance")
+        if bool(((counts == 0) | (counts == H * W)).any()):      # the reference indexes counts[1]: a one-class image raises
+            raise IndexError("index 1 is out of bounds for dimension 0 with size 1")
+        return w
     gt_batch = gt_batch.cpu()
     w_batch = torch.empty_like(gt_batch).float()
     for b in range(gt_batch.shape[0]):
@@ -49,6 +63,14 @@ def IoU(pred, label):
     pred_np = pred.cpu().numpy()
     label_np = label.cpu().numpy()
     return np.sum(np.logical_and(pred_np, label_np)) / np.sum(np.logical_or(pred_np, label_np))
+
+
+def metrics_from_counts(inter, union, diff, size):
+    """IoU and pixel error from the integer counts unet_eval_masks produces on the device."""
+    out = np.empty([2, 1])
+    out[0] = inter / union
+    out[1] = diff / size
+    return out
 
 
 def evaluation_metrics(pred, label):

@@ -19,19 +19,26 @@ import dp as dp_mod
 
 _BASE = 64          # hard-coded in the reference (network.py:23-58)
 
-# (name, kind, cin, cout, k) in the reference's declaration order
-_LAYERS = [
-    ("conv11c", "conv", 1, 64, 3), ("conv12c", "conv", 64, 64, 3),
-    ("conv21c", "conv", 64, 128, 3), ("conv22c", "conv", 128, 128, 3),
-    ("conv31c", "conv", 128, 256, 3), ("conv32c", "conv", 256, 256, 3),
-    ("conv41c", "conv", 256, 512, 3), ("conv42c", "conv", 512, 512, 3),
-    ("conv51c", "conv", 512, 1024, 3), ("conv52c", "conv", 1024, 1024, 3),
-    ("upconv4", "up", 1024, 512, 2), ("conv41e", "conv", 1024, 512, 3), ("conv42e", "conv", 512, 512, 3),
-    ("upconv3", "up", 512, 256, 2), ("conv31e", "conv", 512, 256, 3), ("conv32e", "conv", 256, 256, 3),
-    ("upconv2", "up", 256, 128, 2), ("conv21e", "conv", 256, 128, 3), ("conv22e", "conv", 128, 128, 3),
-    ("upconv1", "up", 128, 64, 2), ("conv11e", "conv", 128, 64, 3), ("conv12e", "conv", 64, 64, 3),
-    ("finalconv", "conv", 64, 2, 1),
-]
+
+def _layers(base=_BASE):
+    """(name, kind, cin, cout, k) in the reference's declaration order; base = first-level width
+    (64 in the reference; 32 is the BASELINE config #5 inference variant)."""
+    c = [base, 2 * base, 4 * base, 8 * base, 16 * base]
+    return [
+        ("conv11c", "conv", 1, c[0], 3), ("conv12c", "conv", c[0], c[0], 3),
+        ("conv21c", "conv", c[0], c[1], 3), ("conv22c", "conv", c[1], c[1], 3),
+        ("conv31c", "conv", c[1], c[2], 3), ("conv32c", "conv", c[2], c[2], 3),
+        ("conv41c", "conv", c[2], c[3], 3), ("conv42c", "conv", c[3], c[3], 3),
+        ("conv51c", "conv", c[3], c[4], 3), ("conv52c", "conv", c[4], c[4], 3),
+        ("upconv4", "up", c[4], c[3], 2), ("conv41e", "conv", c[4], c[3], 3), ("conv42e", "conv", c[3], c[3], 3),
+        ("upconv3", "up", c[3], c[2], 2), ("conv31e", "conv", c[3], c[2], 3), ("conv32e", "conv", c[2], c[2], 3),
+        ("upconv2", "up", c[2], c[1], 2), ("conv21e", "conv", c[2], c[1], 3), ("conv22e", "conv", c[1], c[1], 3),
+        ("upconv1", "up", c[1], c[0], 2), ("conv11e", "conv", c[1], c[0], 3), ("conv12e", "conv", c[0], c[0], 3),
+        ("finalconv", "conv", c[0], 2, 1),
+    ]
+
+
+_LAYERS = _layers()
 
 
 def _init_std(name, cin):
@@ -49,11 +56,11 @@ def _init_std(name, cin):
 _handles = {}
 
 
-def _handle(device_index):
-    h = _handles.get(device_index)
+def _handle(device_index, base=_BASE):
+    h = _handles.get((device_index, base))
     if h is None:
-        h = _hip.Handle(_BASE, device_index)
-        _handles[device_index] = h
+        h = _hip.Handle(base, device_index)
+        _handles[(device_index, base)] = h
     return h
 
 
@@ -77,7 +84,7 @@ class _UnetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, *params):
         dev = x.device.index
-        h = _handle(dev)
+        h = _handle(dev, module.base_ch)
         B, _, S, _ = x.shape
         nbytes = h.workspace_bytes(B, S, True)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -94,7 +101,7 @@ class _UnetFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         params = ctx.saved_tensors
         module = ctx.module
-        h = _handle(ctx.dev)
+        h = _handle(ctx.dev, module.base_ch)
         L = _hip.lib()
         buckets = module._buckets
         flat, grads = buckets.allocate([p.shape for p in params], dlogits.device)
@@ -121,17 +128,21 @@ class Unet(nn.Module):
     valid 3x3 convs, skips taken AFTER the pool and zero-padded to the up-conv size,
     1x1 head without activation; fp32; input [B,1,S,S] with S = 16L+60, L even."""
 
-    def __init__(self):
+    def __init__(self, base_ch=_BASE):
+        """Unet() as in the reference (no arguments).  base_ch is an extension: 32 gives the half-width
+        net of BASELINE config #5 (inference only; the weight-gradient kernels need multiples of 64)."""
         super(Unet, self).__init__()
+        self.base_ch = base_ch
+        self._layer_table = _layers(base_ch)
         # nn.Conv2d / nn.ConvTranspose2d serve ONLY as parameter containers with the reference's
         # names, shapes and default-init RNG consumption (their forward is never called).
-        for name, kind, cin, cout, k in _LAYERS:
+        for name, kind, cin, cout, k in self._layer_table:
             if kind == "conv":
                 setattr(self, name, nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=k))
             else:
                 setattr(self, name, nn.ConvTranspose2d(in_channels=cin, out_channels=cout, kernel_size=k, stride=k))
         # weights are then re-drawn in declaration order (network.py:70-105), biases keep the default
-        for name, kind, cin, cout, k in _LAYERS:
+        for name, kind, cin, cout, k in self._layer_table:
             m = getattr(self, name)
             m.weight = nn.Parameter(torch.empty_like(m.weight).normal_(mean=0, std=_init_std(name, cin)))
         self._dp = None
@@ -151,7 +162,7 @@ class Unet(nn.Module):
 
     def _params(self):
         out = []
-        for name, _, _, _, _ in _LAYERS:
+        for name, _, _, _, _ in self._layer_table:
             m = getattr(self, name)
             out.append(m.weight)
             out.append(m.bias)
@@ -184,7 +195,7 @@ class Unet(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _UnetFunction.apply(t, self, *params)
         # inference (trainer.py:95 no_grad): no activation-gradient storage
-        h = _handle(t.device.index)
+        h = _handle(t.device.index, self.base_ch)
         B, _, S, _ = t.shape
         nbytes = h.workspace_bytes(B, S, False)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)

@@ -100,3 +100,22 @@ class SGD(torch.optim.Optimizer):
                     _hip.check(_hip.lib().unet_sgd_momentum(_hip.ptr_table(chunk), _hip.ptr_table(grads), _hip.ptr_table(bufs),
                                                             numel, len(chunk), float(group["lr"]), float(group["momentum"]),
                                                             is_first, _hip.stream()), "unet_sgd_momentum")
+
+
+def crop_argmax_metrics(preds, labels=None):
+    """Fused back end of the test/validation step (tester.py:29-42): centre-crop `preds` [B,2,So,So] to the
+    label size, argmax over the two classes, and (with int64 labels [B,1,n,n] or [B,n,n]) count
+    sum(pred&label), sum(pred|label), sum|pred-label| per image.  Returns (mask int64 [B,n,n], stats int64 [B,3] | None)."""
+    B, two, So, _ = preds.shape
+    assert two == 2 and preds.stride(3) == 1
+    if labels is not None:
+        labels = labels.to(preds.device).reshape(B, labels.shape[-2], labels.shape[-1]).contiguous()
+        n = labels.shape[-1]
+    else:
+        n = So
+    pad = int((So - n) / 2)
+    mask = torch.empty(B, n, n, dtype=torch.int64, device=preds.device)
+    stats = torch.empty(B, 3, dtype=torch.int64, device=preds.device) if labels is not None else None
+    _hip.check(_hip.lib().unet_eval_masks(_hip.ptr(preds), preds.stride(0), preds.stride(1), preds.stride(2), pad, _hip.ptr(labels),
+                                          _hip.ptr(mask), B, n, _hip.ptr(stats), _hip.stream()), "unet_eval_masks")
+    return mask, stats

@@ -8,7 +8,7 @@ from time import time
 import numpy as np
 import torch
 
-from functions import evaluation_metrics
+from functions import evaluation_metrics, metrics_from_counts
 import optim as hip_optim
 
 
@@ -40,7 +40,8 @@ def testing(unet, test_loader, batch_size, device, output_dir):
         with torch.no_grad():      # the reference leaves autograd on here (Q8); only memory differs
             pred = unet(image.to(device))
         pad = int((pred.shape[-1] - label.shape[-1]) / 2)
-        pred = hip_optim.argmax2(pred[:, :, pad:label.shape[-1] + pad, pad:label.shape[-1] + pad])
+        # crop + argmax + IoU / pixel-error counts in one pass on the device (no per-image mask download)
+        pred, stats = hip_optim.crop_argmax_metrics(pred, label)
 
         save_image(image[0, 0, pad:label.shape[-1] + pad, pad:label.shape[-1] + pad], os.path.join(output_dir, 'images', f'image{idx}.tif'))
         save_image(label[0, 0, :, :].float(), os.path.join(output_dir, 'labels', f'label{idx}.tif'))
@@ -48,7 +49,8 @@ def testing(unet, test_loader, batch_size, device, output_dir):
         idx += 1
 
         if test_eval is None:      # Q5: the reference keeps only the first sample's metrics
-            test_eval = evaluation_metrics(pred[0, :, :].detach(), label[0, 0, :, :].detach())
+            inter, union, diff = [int(v) for v in stats[0].tolist()]
+            test_eval = metrics_from_counts(inter, union, diff, label.shape[-1] * label.shape[-2])
 
     test = np.mean(test_eval, axis=1)
     test_std = np.std(test_eval, axis=1)

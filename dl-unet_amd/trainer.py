@@ -5,7 +5,8 @@
     loss (L1)          BCEWithLogitsLoss(weight=class map)  -> unet_bce_logits (fwd + grad in one pass)
     backward           loss.backward()                     -> unet_backward_stage x6 (+ RCCL all-reduce if DP)
     update (L3)        SGD(lr=1e-4, momentum=0.99)          -> unet_sgd_momentum
-    prediction (L2)    preds.argmax(dim=1)                 -> unet_argmax2
+    prediction (L2)    preds.argmax(dim=1) + IoU/PE        -> unet_eval_masks (fused crop+argmax+counts)
+    weight map (N3)    class_balance(labels)               -> unet_class_balance
 
 Reference behaviours kept on purpose: Q3 the dataset-name comparisons are identity
 tests in the reference and are False for names arriving from argv, so no stop goal is armed and
@@ -18,7 +19,7 @@ from time import time
 import numpy as np
 import torch
 
-from functions import class_balance, evaluation_metrics
+from functions import class_balance, metrics_from_counts
 import optim as hip_optim
 
 
@@ -34,12 +35,20 @@ def _goal_for(DATASET):
 
 def _step_loss(unet, images, labels, device, train):
     preds = unet(images.to(device))
+    labels = labels.to(device)                                  # everything below stays on the device
     pad = int((preds.shape[-1] - labels.shape[-1]) / 2)
     preds = preds[:, :, pad:labels.shape[-1] + pad, pad:labels.shape[-1] + pad]
     ll = hip_optim.onehot2(labels, preds)                       # [1-y, y] (trainer.py:63-66)
-    weight_maps = class_balance(labels.squeeze(1)).to(device)   # [B,H,W] (trainer.py:72)
+    weight_maps = class_balance(labels.squeeze(1))              # [B,H,W] (trainer.py:72), unet_class_balance
     loss = hip_optim.bce_with_logits(preds, ll, weight=weight_maps)
-    return preds, loss
+    return preds, loss, labels
+
+
+def _first_sample_metrics(preds, labels):
+    """argmax + IoU / pixel error of the batch in one device pass; only sample 0 is kept (quirk Q5)."""
+    _, stats = hip_optim.crop_argmax_metrics(preds.detach(), labels)
+    inter, union, diff = [int(v) for v in stats[0].tolist()]
+    return metrics_from_counts(inter, union, diff, labels.shape[-1] * labels.shape[-2])
 
 
 def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_dir, DATASET):
@@ -67,22 +76,20 @@ def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_di
 
         for images, labels in train_loader:
             optimizer.zero_grad()
-            preds, loss = _step_loss(unet, images, labels, device, True)
+            preds, loss, labels = _step_loss(unet, images, labels, device, True)
             loss.backward()
             optimizer.step()
             total_loss += loss.detach()
-            masks = hip_optim.argmax2(preds.detach())
             if train_eval is None:                              # Q5: first sample of the epoch only
-                train_eval = evaluation_metrics(masks[0].detach(), labels[0, 0, :, :].detach())
+                train_eval = _first_sample_metrics(preds, labels)
         train_eval_epoch = np.mean(train_eval, axis=1)
 
         with torch.no_grad():
             for images, labels in val_loader:
-                preds, loss = _step_loss(unet, images, labels, device, False)
+                preds, loss, labels = _step_loss(unet, images, labels, device, False)
                 total_loss_val += loss
-                masks = hip_optim.argmax2(preds)
                 if val_eval is None:
-                    val_eval = evaluation_metrics(masks[0].detach(), labels[0, 0, :, :].detach())
+                    val_eval = _first_sample_metrics(preds, labels)
         val_eval_epoch = np.mean(val_eval, axis=1)
 
         scheduler.step(total_loss_val / (len(val_loader) * batch_size))

@@ -132,6 +132,27 @@ int unet_sgd_momentum(void *const *params, const void *const *grads, void *const
                       const size_t *numel, int n, float lr, float mu, int first_step,
                       void *stream);
 
+/* ---- callers either side of the path; fp32 images [B,H,W], int64 labels ----------
+ * N2 overlap-tile front end, replaces mirror_transform + the [0,1] normalisation (data.py:184-188,
+ * :249-277): out[b,0,Y,X] = x[b, r(Y), r(X)] with the reference's asymmetric reflection (top/left band
+ * without the edge pixel, bottom/right band with it); minmax (from unet_minmax, [B][2]) may be NULL.   */
+int unet_minmax(const void *x, int B, size_t n_per_image, void *out_minmax, void *stream);
+int unet_mirror_pad(const void *x, int B, int n, int S, const void *minmax, void *out, void *stream);
+/* N2 back end, replaces pred[:, :, pad:pad+n, pad:pad+n].argmax(dim=1) + IoU / Pixel_error counting
+ * (tester.py:29-42, functions.py:174-213): mask int64 [B,n,n]; with labels int64 [B,n,n]:
+ * stats u64 [B][3] = {sum(pred&label), sum(pred|label), sum|pred-label|} (exact integer atomics).      */
+int unet_eval_masks(const void *logits, long batch_stride, long plane_stride, long row_stride, int pad,
+                    const void *labels_i64, void *mask_i64, int B, int n, void *stats_u64, void *stream);
+/* N3, replaces functions.class_balance (functions.py:82-117) for {0,1} labels: w = 1 on cells,
+ * count(1)/count(0) on background; counts_u64 [B] receives count(1) (caller checks the degenerate case). */
+int unet_class_balance(const void *labels_i64, int B, int H, int W, void *weights, void *counts_u64, void *stream);
+/* N1, replaces elastic_transform's two steps (data.py:225-245): scipy.ndimage.gaussian_filter(field,
+ * sigma, mode="constant") * scale as two 1-D passes with the caller's normalised taps [2*radius+1], and
+ * map_coordinates(img, (row+dy, col+dx), order=1) (bilinear, 0 outside [0,n-1]).                       */
+int unet_gaussian_filter(const void *field, int B, int H, int W, const void *weights, int radius, float scale,
+                         void *tmp, void *out, void *stream);
+int unet_warp_bilinear(const void *img, const void *dy, const void *dx, int B, int H, int W, void *out, void *stream);
+
 /* ---- per-op entry points (NHWC fp32), used by the unit tests ---------------------------------
  * Each replaces the ATen op dispatched at the cited line.  w_* are in reference layout.    */
 /* nn.Conv2d(3x3, valid)+ReLU, network.py:131-188.  Second source (x2) is the virtual

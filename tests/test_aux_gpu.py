@@ -1,0 +1,112 @@
+"""GPU kernels either side of the hot path against the pinned numpy/scipy oracle
+(oracle/aux_ref.py) and the reference's goldens.  Integer results bit-exact; float results <= 2e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import _hip
+    _hip.lib()
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return torch.device("cuda:0")
+
+
+def test_mirror_transform_bit_exact(dev, golden_dir):
+    import data
+    from oracle import aux_ref, prng
+    g = np.load(os.path.join(golden_dir, "aux_golden.npz"))
+    for n in (196, 388, 512):
+        img = prng.uniform01(7, 50 + n, n * n).reshape(n, n).astype(np.float32)
+        m = data.mirror_transform(torch.from_numpy(img).to(dev)).cpu().numpy()
+        ref = aux_ref.mirror_transform(img)
+        assert m.shape == ref.shape and np.array_equal(m, ref)           # a pure gather: bit-exact
+    n = 196                                                              # index-encoding image against the reference golden
+    enc = (np.arange(n)[:, None] * 1000.0 + np.arange(n)[None, :]).astype(np.float32)
+    m = data.mirror_transform(torch.from_numpy(enc).to(dev)).cpu().numpy()
+    assert np.array_equal(m[0], g["mirror_196_row0"]) and np.array_equal(m[:, 0], g["mirror_196_col0"])
+    assert np.array_equal(np.diagonal(m), g["mirror_196_diag"]) and np.array_equal(m[-1], g["mirror_196_last"])
+    # batched + normalised front end (ImageDataset_test): mirror then (x-min)/ptp per image
+    batch = np.stack([prng.uniform01(8, i, n * n).reshape(n, n) * (i + 1) + i for i in range(3)]).astype(np.float32)
+    out = data.test_input(torch.from_numpy(batch).to(dev)).cpu().numpy()
+    for i in range(3):
+        ref = aux_ref.normalise01(aux_ref.mirror_transform(batch[i].astype(np.float64)))
+        assert np.abs(out[i, 0] - ref).max() < 2e-6
+    with pytest.raises(RuntimeError):                                    # too small to mirror into its input size
+        data.mirror_transform(torch.zeros(36, 36, device=dev))
+
+
+def test_elastic_transform_vs_reference_golden(dev, golden_dir):
+    import data
+    from oracle import prng
+    g = np.load(os.path.join(golden_dir, "aux_golden.npz"))
+    for tag in ("a", "b"):
+        alpha, sigma, H, seed = g["elastic_%s_params" % tag]
+        H = int(H)
+        img = prng.uniform01(7, 1, H * H).reshape(H, H) * 255.0
+        tgt = (prng.uniform01(7, 2, H * H).reshape(H, H) > 0.5) * 255.0
+        a, b = data.elastic_transform((torch.from_numpy(img).float().to(dev), torch.from_numpy(tgt).float().to(dev)),
+                                      alpha=float(alpha), sigma=float(sigma), random_state=np.random.RandomState(int(seed)))
+        # fp32 warp of 0..255 images: the displacement field itself carries fp32 rounding (alpha * 1e-7),
+        # which moves a bilinear sample of a 0/255 mask by up to ~1e-3; tolerance 2e-5 of the value range
+        assert np.abs(a.cpu().numpy() - g["elastic_%s_img" % tag]).max() < 255 * 2e-5
+        assert np.abs(b.cpu().numpy() - g["elastic_%s_tgt" % tag]).max() < 255 * 2e-5
+    # batched, device RNG: shapes and the identity for alpha = 0
+    x = torch.rand(3, 40, 40, device=dev)
+    (y,) = data.elastic_transform((x,), alpha=0.0, sigma=3.0)
+    assert torch.equal(x, y)
+
+
+def test_class_balance_and_metrics_bit_exact(dev, golden_dir):
+    import functions
+    import optim as hip_optim
+    from oracle import aux_ref, prng
+    ka = np.load(os.path.join(golden_dir, "known_answers.npz"))
+    lab = torch.from_numpy(prng.make_labels(3, 2, 36)[:, 0]).to(dev)
+    w = functions.class_balance(lab)
+    assert w.is_cuda and np.array_equal(w.cpu().numpy(), ka["class_balance_rand"])
+    # fused crop + argmax + counts against the oracle on a strided, padded logits tensor
+    B, So, n = 3, 52, 36
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(B, 2, So, So, generator=g)
+    labels = torch.from_numpy(prng.make_labels(21, B, n))
+    mask, stats = hip_optim.crop_argmax_metrics(logits.to(dev), labels.to(dev))
+    pad = (So - n) // 2
+    ref_mask = logits[:, :, pad:pad + n, pad:pad + n].argmax(dim=1).numpy()
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+    for b in range(B):
+        assert tuple(stats[b].tolist()) == aux_ref.eval_counts(ref_mask[b], labels[b, 0].numpy())
+    m = functions.metrics_from_counts(*[int(v) for v in stats[0].tolist()], n * n)
+    assert np.allclose(m, functions.evaluation_metrics(torch.from_numpy(ref_mask[0]), labels[0, 0]))
+
+
+def test_config5_overlap_tile_inference_base32(dev):
+    """BASELINE config #5 shape at reduced batch: 1024^2 images -> mirror to 1212 -> 32-base-ch net ->
+    crop/argmax/pixel-error, end to end on the device, against the torch restatement on the host."""
+    import data
+    import network
+    import optim as hip_optim
+    from oracle import aux_ref, prng, torch_ref
+    torch.manual_seed(0)
+    net = network.Unet(base_ch=32).to(dev)
+    n, B = 1024, 1
+    imgs = torch.from_numpy(prng.uniform01(31, 0, B * n * n).reshape(B, n, n).astype(np.float32) * 255)
+    labels = torch.from_numpy(prng.make_labels(32, B, n))
+    x = data.test_input(imgs.to(dev))
+    assert x.shape == (B, 1, 1212, 1212)
+    with torch.no_grad():
+        y = net(x)
+    assert y.shape == (B, 2, 1028, 1028)
+    mask, stats = hip_optim.crop_argmax_metrics(y, labels.to(dev))
+    p = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    xr = torch.from_numpy(aux_ref.normalise01(aux_ref.mirror_transform(imgs[0].double().numpy()))).float()[None, None]
+    yr = torch_ref.unet_forward(p, xr)
+    assert ((y.cpu() - yr).abs().max() / yr.abs().max()).item() < 2e-5
+    with pytest.raises(RuntimeError):                # training needs base_ch % 64 == 0 (weight-gradient tiles)
+        net(x).sum().backward()

@@ -1,0 +1,46 @@
+"""Pins oracle/aux_ref.py (numpy/scipy restatement of mirror_transform, elastic_transform, metrics,
+class_balance) against goldens produced by the reference's own functions.  CPU only."""
+import os
+
+import numpy as np
+
+from oracle import aux_ref, prng
+
+
+def test_mirror_transform_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "aux_golden.npz"))
+    for n in (196, 388):
+        img = (np.arange(n)[:, None] * 1000.0 + np.arange(n)[None, :]).astype(np.float64)
+        m = aux_ref.mirror_transform(img)
+        assert tuple(g["mirror_%d_shape" % n]) == m.shape
+        assert np.array_equal(m[0], g["mirror_%d_row0" % n]) and np.array_equal(m[:, 0], g["mirror_%d_col0" % n])
+        assert np.array_equal(np.diagonal(m), g["mirror_%d_diag" % n]) and np.array_equal(m[-1], g["mirror_%d_last" % n])
+        rnd = prng.uniform01(7, 50 + n, n * n).reshape(n, n)
+        mr = aux_ref.mirror_transform(rnd)
+        assert np.allclose([mr.sum(), (mr * mr).sum(), mr[::7, ::5].sum()], g["mirror_%d_rand_sum" % n], rtol=1e-13)
+
+
+def test_elastic_transform_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "aux_golden.npz"))
+    for tag in ("a", "b"):
+        alpha, sigma, H, seed = g["elastic_%s_params" % tag]
+        H = int(H)
+        img = prng.uniform01(7, 1, H * H).reshape(H, H) * 255.0
+        tgt = (prng.uniform01(7, 2, H * H).reshape(H, H) > 0.5) * 255.0
+        rs = np.random.RandomState(int(seed))
+        (a, b), _, _ = aux_ref.elastic_transform((img, tgt), alpha, sigma, (rs.rand(H, H), rs.rand(H, H)))
+        assert np.abs(a - g["elastic_%s_img" % tag]).max() < 1e-9
+        assert np.abs(b - g["elastic_%s_tgt" % tag]).max() < 1e-9
+
+
+def test_metrics_and_class_balance(golden_dir):
+    g = np.load(os.path.join(golden_dir, "aux_golden.npz"))
+    ka = np.load(os.path.join(golden_dir, "known_answers.npz"))
+    p = prng.make_labels(11, 1, 64)[0, 0]; l = prng.make_labels(12, 1, 64)[0, 0]
+    inter, union, diff = aux_ref.eval_counts(p, l)
+    assert np.allclose([inter / union, diff / p.size], g["evalm_rand"].ravel(), rtol=1e-14)
+    lab = prng.make_labels(3, 2, 36)[:, 0]
+    for b in range(2):
+        assert np.array_equal(aux_ref.class_balance(lab[b]), ka["class_balance_rand"][b])
+    w, r = aux_ref.gaussian_taps(10.0)
+    assert r == 40 and abs(w.sum() - 1) < 1e-15
