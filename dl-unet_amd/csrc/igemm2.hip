@@ -29,11 +29,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// wait until at most `stages` whole stages (G LDS-DMA instructions each) are still in flight
+template <int G> __device__ __forceinline__ void wait_stages(int stages)
+{
+    switch (stages) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<G>(); break;
+    case 2: wait_vmcnt<2 * G>(); break;
+    case 3: wait_vmcnt<3 * G>(); break;
+    case 4: wait_vmcnt<4 * G>(); break;
+    default: wait_vmcnt<5 * G>(); break;
+    }
+}
 
 struct Frags { f32x4 a[2][2]; f32x4 b[2][2]; };      // [tile][k8 half]
 
-template <int BM, int BN, bool PAD>
-__global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm2_f32_kernel(const IgemmP p)
+template <int BM, int BN, bool PAD, int NST>
+__global__ __launch_bounds__(256, 2) void igemm2_f32_kernel(const IgemmP p)
 {
     constexpr int WN = BN / 64, WM = 4 / WN;
     static_assert(WM * 64 == BM, "4 waves of 64x64");
@@ -156,10 +168,9 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm2_f32_kernel(co
 
     const int nk = p.Kd >> 4;
     setup_source(0);
-    stage(0); advance();
-    if (nk > 1) { stage(1); advance(); }
-    if (nk > 2) { stage(2); advance(); }
-    if (nk > 2) wait_vmcnt<2 * G>(); else if (nk > 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+    int issued = 0;
+    for (; issued < NST && issued < nk; ++issued) { stage(issued); advance(); }
+    wait_stages<G>(issued - 1);
     __builtin_amdgcn_s_barrier();
     Frags f0, f1;
     read_frags(f0, 0);
@@ -168,10 +179,12 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm2_f32_kernel(co
     auto step = [&](int s, const Frags &cur, Frags &nxt) {
         mfma_half(cur, 0);
         if (s + 1 < nk) {
-            if (s + 2 < nk) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            // in flight: stages s+1 .. min(s+NST-1, nk-1); stage s+1 must have landed
+            const int inflight = (nk - 1 - s) < (NST - 1) ? (nk - 1 - s) : (NST - 1);
+            wait_stages<G>(inflight - 1);
             __builtin_amdgcn_s_barrier();
-            if (s + 3 < nk) { stage(s % 3); advance(); }
-            read_frags(nxt, (s + 1) % 3);
+            if (s + NST < nk) { stage(s % NST); advance(); }
+            read_frags(nxt, (s + 1) % NST);
         }
         mfma_half(cur, 1);
     };
@@ -259,12 +272,12 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : 2)) void igemm2_f32_kernel(co
 
 double igemm_alg_flops(const IgemmP &p);
 
-template <int BM, int BN, bool PAD>
+template <int BM, int BN, bool PAD, int NST>
 static int launch_cfg2(const IgemmP &p, hipStream_t st)
 {
-    constexpr int LDS = 3 * (BM + BN) * 64;
+    constexpr int LDS = NST * (BM + BN) * 64;
     static bool attr_done = false;
-    auto kern = igemm2_f32_kernel<BM, BN, PAD>;
+    auto kern = igemm2_f32_kernel<BM, BN, PAD, NST>;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
@@ -283,8 +296,10 @@ static int launch_cfg2(const IgemmP &p, hipStream_t st)
 
 int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st)
 {
-    if (p.Nn % 128 == 0) return pad ? launch_cfg2<128, 128, true>(p, st) : launch_cfg2<128, 128, false>(p, st);
-    return pad ? launch_cfg2<256, 64, true>(p, st) : launch_cfg2<256, 64, false>(p, st);
+    // K step 16: 5 stages of 16 KiB (128x128) / 4 stages of 20 KiB (256x64) = 80 KiB -> 2 workgroups per CU,
+    // LDS-DMA issued 4 (3) steps ahead of its consumer
+    if (p.Nn % 128 == 0) return pad ? launch_cfg2<128, 128, true, 5>(p, st) : launch_cfg2<128, 128, false, 5>(p, st);
+    return pad ? launch_cfg2<256, 64, true, 4>(p, st) : launch_cfg2<256, 64, false, 4>(p, st);
 }
 
 }  // namespace unet
