@@ -270,3 +270,53 @@ def test_data_parallel_module_path_two_ranks_one_gpu(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     assert "WORST" in outs[0]
+
+
+def test_full_size_S572_gradients_on_same_branch():
+    """The BASELINE tile size itself: every gradient element of one 572x572 tile against the fp64 C oracle on the
+    HIP forward's ReLU/pool branch (the oracle takes ~1 min on the host cores)."""
+    from oracle import parity
+    r = parity.check_same_branch(572, 1)
+    assert r["fwd"] < FWD_TOL, r["fwd"]
+    worst = max(r["grads"].items(), key=lambda kv: kv[1])
+    assert worst[1] < GRAD_TOL, worst
+
+
+def test_config4_shaped_training_loop_with_gpu_augmentation(tmp_path):
+    """BASELINE config #4 at reduced scale: 512x512-shaped synthetic cell images -> device-side augmentation
+    (mirror-pad to the 700 input, elastic deformation alpha=200 sigma=10 shared by image and mask, threshold,
+    crop to the 516 output) -> trainer.training() for one epoch at B=2 -> IoU / pixel error files."""
+    import data
+    import network
+    from trainer import training
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n, S = 512, 700
+    yy, xx = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+
+    def sample(seed):
+        g = torch.Generator().manual_seed(seed)
+        mask = torch.zeros(n, n)
+        for _ in range(12):                                   # blobs = "cells"
+            cy, cx, r = torch.randint(40, n - 40, (1,), generator=g), torch.randint(40, n - 40, (1,), generator=g), torch.randint(15, 45, (1,), generator=g)
+            mask = torch.maximum(mask, ((yy - cy) ** 2 + (xx - cx) ** 2 < r * r).float())
+        img = (0.3 + 0.5 * mask + 0.1 * torch.rand(n, n, generator=g)) * 255
+        return img, mask * 255
+
+    def batch(seeds):
+        imgs, masks = zip(*[sample(s) for s in seeds])
+        imgs = torch.stack(imgs).to(dev); masks = torch.stack(masks).to(dev)
+        x = data.mirror_transform(imgs)[:, 0]                 # [B,700,700] network input size
+        m = data.mirror_transform(masks)[:, 0]
+        x, m = data.elastic_transform((x, m), alpha=200, sigma=10)     # same field for image and mask
+        pad = (S - n) // 2
+        gt = (m[:, pad:pad + n, pad:pad + n] > 127).long()[:, None]    # threshold + crop (data.py:130-133)
+        lo = x.amin(dim=(1, 2), keepdim=True); hi = x.amax(dim=(1, 2), keepdim=True)
+        return ((x - lo) / (hi - lo))[:, None].contiguous(), gt.contiguous()
+
+    net = network.Unet().to(dev)
+    training(net, [batch((1, 2))], [batch((3, 4))], 0, 2, dev, str(tmp_path), "DIC-C2DH-HeLa")
+    iou = np.loadtxt(os.path.join(tmp_path, "progress", "val_eval_iou.out"))
+    pe = np.loadtxt(os.path.join(tmp_path, "progress", "val_eval_pe.out"))
+    assert 0.0 <= float(iou) <= 1.0 and 0.0 <= float(pe) <= 1.0
+    assert np.isfinite(np.loadtxt(os.path.join(tmp_path, "progress", "loss.out")))
