@@ -36,7 +36,14 @@ def cpu_baseline(max_seconds=30.0):
     tests/test_oracle_golden.py) on a bounded sample: B=1 tiles of 572^2, fwd+bwd+SGD steps."""
     import numpy as np
     from oracle import prng, torch_ref
-    cores = torch.get_num_threads()
+    # the GPU box gives one GPU's share of the host (16 cores); torch's default of one thread per visible
+    # core (128) oversubscribes that share and runs slower
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
+    torch.set_num_threads(cores)
     p = torch_ref.params_to_torch(prng.make_params(0), torch.float32, requires_grad=True)
     mom = {}
     x = torch.from_numpy(prng.make_input(1, 1, S))
