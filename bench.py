@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for one rank")
+    ap.add_argument("--math", type=int, default=0, choices=(0, 1, 2),
+                    help="arithmetic of the dense contractions for the MAIN measurement: 0 exact fp32 MFMA (default, the "
+                         "BASELINE config), 1 bf16x3 split, 2 bf16 compute (include/unet_hip.h unet_set_math)")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the short extra measurements of the other math modes")
     ap.add_argument("--dump-launches", default=None, help="write per-launch timings (CSV) of the timed region here")
     args = ap.parse_args()
 
@@ -95,6 +99,7 @@ def main():
     import optim as hip_optim
     L = _hip.lib()
 
+    _hip.check(L.unet_set_math(args.math), "unet_set_math")
     torch.manual_seed(0)                                   # same initial weights on every rank
     net = network.Unet().to(dev)
     if use_dist:
@@ -147,7 +152,8 @@ def main():
             "metric": "572x572 tiles/sec fwd+bwd", "value": tiles / dt, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {0: "f32", 1: "bf16x3 (fp32 accumulate/storage)", 2: "bf16 (fp32 accumulate/storage)"}[args.math],
+            "data": "synthetic",
             "config": {"workload": "batch=%d/GPU 572x572x1 fwd+bwd+SGD fp32, 64-base-ch U-Net (BASELINE configs[1])" % B,
                        "global_batch": B * world, "tile": S, "parallelism": "dp%d" % world,
                        "loss": "unweighted BCE-with-logits", "final_loss": float(loss.item())},
@@ -178,6 +184,28 @@ def main():
                               for k, v in fam.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    # informational: the same step in the other arithmetic modes (not part of `value`)
+    if not args.no_other_modes:
+        other = {}
+        for m, name in ((1, "bf16x3_split_fp32_accumulate"), (2, "bf16_compute_fp32_accumulate")):
+            if m == args.math:
+                continue
+            _hip.check(L.unet_set_math(m), "unet_set_math")
+            for _ in range(2):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step()
+            barrier()
+            tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            other[name] = {"tiles_per_s": B * world * 5 / tm.item(), "ms_per_step": tm.item() / 5 * 1e3}
+        _hip.check(L.unet_set_math(args.math), "unet_set_math")
+        if rank == 0:
+            out["other_math_modes"] = other
+    if rank == 0:
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -19,6 +19,8 @@ vp = C.c_void_p
 _SIGS = {
     "unet_last_error": (C.c_char_p, []),
     "unet_abi_version": (C.c_int, []),
+    "unet_set_math": (C.c_int, [C.c_int]),
+    "unet_get_math": (C.c_int, []),
     "unet_create": (C.c_int, [C.POINTER(vp), vp]),
     "unet_destroy": (C.c_int, [vp]),
     "unet_output_size": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),

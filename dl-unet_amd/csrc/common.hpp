@@ -71,6 +71,8 @@ struct IgemmP {
     int mtiles, ntiles;
 };
 int launch_igemm(IgemmP p, hipStream_t st);
+int get_math_mode();
+void set_math_mode(int m);
 
 // ---------------------------------------------------------------------------------------------
 // Weight-gradient descriptor (wgrad.hip):  D[t][i][j] = sum_{img,y,x} X[img][(y+oy0)*s+ty-xpad][(x+ox0)*s+tx-xpad][xc0+i]

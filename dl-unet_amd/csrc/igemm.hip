@@ -24,6 +24,12 @@
 namespace unet {
 
 int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st);
+int launch_igemmx(const IgemmP &p, bool pad, int nsplit, hipStream_t st);
+
+// 0 = exact fp32 MFMA (default), 1 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores), 2 = bf16 compute
+static int g_math_mode = [] { const char *e = getenv("UNET_MATH"); return e ? atoi(e) : 0; }();
+int get_math_mode() { return g_math_mode; }
+void set_math_mode(int m) { g_math_mode = m; }
 
 #define GLDS16(gptr, lptr)                                                                    \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
@@ -237,6 +243,8 @@ int launch_igemm(IgemmP p, hipStream_t st)
         ARG_CHECK((size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C < 0x7FFFFFFFull, "igemm: source exceeds 31-bit element offsets");
     p.zeros = zero_page();
     if (!p.zeros) return -2;
+    if (g_math_mode == 1) return launch_igemmx(p, pad, 3, st);
+    if (g_math_mode == 2) return launch_igemmx(p, pad, 1, st);
     static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();
     if (gen == 2 && p.scatter != 2 && p.rw1 <= p.rw0) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
     if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true>(p, st) : launch_cfg<128, 128, false>(p, st);

@@ -300,6 +300,14 @@ extern "C" {
 const char *unet_last_error(void) { return g_err; }
 int unet_abi_version(void) { return 1; }
 
+int unet_set_math(int mode)
+{
+    ARG_CHECK(mode >= 0 && mode <= 2, "unet_set_math: mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (bf16)");
+    set_math_mode(mode);
+    return 0;
+}
+int unet_get_math(void) { return get_math_mode(); }
+
 int unet_create(unet_handle **out, const unet_config *cfg)
 {
     ARG_CHECK(out && cfg, "unet_create: null argument");

@@ -21,6 +21,8 @@
 
 namespace unet {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 #define GLDS16(gptr, lptr)                                                                    \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
@@ -37,7 +39,7 @@ struct WgradK {               // kernel-side copy with the derived decomposition
 template <int TY, int TX, int S>
 struct WgradGeom {
     static constexpr int T = TY * TX;
-    static constexpr int XPX = ((PWMAX - 1) * S + TX + 3) / 4 * 4;   // staged X pixels per row
+    static constexpr int XPX = ((PWMAX - 1) * S + TX + 3) / 4 * 4;   // staged X pixels per row (the bf16 path reads up to (PWMAX-1)*S + TX - 1 too)
     static constexpr int XGROUPS = XPX / 4;
     static constexpr int YGROUPS = PWMAX / 4;
     static constexpr int RING = 4;                                    // X row slots (>= TY + S)
@@ -47,8 +49,8 @@ struct WgradGeom {
     static_assert(TY + S <= RING, "ring too small");
 };
 
-template <int TY, int TX, int S>
-__global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(const WgradK k)
+template <int TY, int TX, int S, int NSPLIT>   // NSPLIT 0: exact fp32 MFMA; 1: bf16; 3: bf16x3 split (see igemmx.hip)
+__global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void wgrad_f32_kernel(const WgradK k)
 {
     using G = WgradGeom<TY, TX, S>;
     constexpr int T = G::T;
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
                 for (int px = bpg; px < pwv; px += 4) bsum += yb_[px * 64];
             }
             const unsigned char *yrow = ys + cur * G::YBUF + b_lane;
+            if constexpr (NSPLIT == 0) {
             for (int q = 0; q < npairs; ++q) {
                 const int pix = 2 * q + lh;
                 const float b = *(const float *)(yrow + pix * 256);
@@ -153,6 +156,45 @@ __global__ __launch_bounds__(256, (TY * TX == 9 ? 3 : 2)) void wgrad_f32_kernel(
                     for (int tx = 0; tx < TX; ++tx) {
                         const float a = *(const float *)(xrow + (pix * S + tx) * 256);
                         acc[ty * TX + tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ty * TX + tx], 0, 0, 0);
+                    }
+                }
+            }
+            } else {
+                // bf16 matrix cores (v_mfma_f32_32x32x16_bf16, K = 16 pixels): lane half h supplies pixels 8h..8h+7.
+                // fp32 values are read from the LDS strips and split into hi (+ lo) bf16 in registers.
+                for (int g16 = 0; g16 * 16 < pwv; ++g16) {
+                    const int pix0 = g16 * 16 + 8 * lh;
+                    float yv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) yv[j] = *(const float *)(yrow + (pix0 + j) * 256);
+                    bf16x8 bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { bh[j] = (__bf16)yv[j]; if (NSPLIT == 3) bl[j] = (__bf16)(yv[j] - (float)bh[j]); }
+#pragma unroll
+                    for (int ty = 0; ty < TY; ++ty) {
+                        const unsigned char *xrow = xs + ((xr0 + ty) & (G::RING - 1)) * G::XSLOT + a_lane;
+                        // the TX taps of this filter row read a sliding window of 8*S + TX - S pixels
+                        constexpr int NV = 7 * S + TX;
+                        float xv[NV];
+                        __bf16 xh[NV], xl[NV];
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) {
+                            xv[j] = *(const float *)(xrow + (pix0 * S + j) * 256);
+                            xh[j] = (__bf16)xv[j];
+                            if (NSPLIT == 3) xl[j] = (__bf16)(xv[j] - (float)xh[j]);
+                        }
+#pragma unroll
+                        for (int tx = 0; tx < TX; ++tx) {
+                            bf16x8 ah, al;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { ah[j] = xh[j * S + tx]; if (NSPLIT == 3) al[j] = xl[j * S + tx]; }
+                            const int t = ty * TX + tx;
+                            if (NSPLIT == 3) {
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                            }
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -243,7 +285,7 @@ static void decompose(const WgradP &p, WgradK &k)
     // Choose rows-per-chunk r and ngroups to minimise  rounds(ngroups*ntile / resident slots) x ceil(nparts/ngroups) x r
     // (all workgroups of a launch do the same per-row work), preferring fewer groups (slab traffic) on ties.
     const int ntile = k.ntile_i * k.ntile_j;
-    const int slots = 256 * (p.TY == 3 ? 3 : 2);
+    const int slots = 256 * ((p.TY == 3 && get_math_mode() == 0) ? 3 : 2);
     const long per_chunk = (long)p.NB * k.nstrips;
     // the search is a few million cheap iterations: memoise per shape (hot calls hit the cache)
     static std::mutex mu;
@@ -309,18 +351,18 @@ static double wgrad_alg_flops(const WgradP &p)
     return 2.0 * p.NB * (double)cy * (double)cx * p.Ci * p.Cj;
 }
 
-template <int TY, int TX, int S>
+template <int TY, int TX, int S, int NSPLIT>
 static int launch_wgrad_t(const WgradK &k, hipStream_t st)
 {
     using G = WgradGeom<TY, TX, S>;
     static bool attr_done = false;
-    auto kern = wgrad_f32_kernel<TY, TX, S>;
+    auto kern = wgrad_f32_kernel<TY, TX, S, NSPLIT>;
     if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         attr_done = true;
     }
     char tag[96];
-    snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
+    snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d;split%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, NSPLIT, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
              k.p.ywin1 - k.p.ywin0, k.nparts, k.pw, k.rows_per_chunk, k.ngroups);
     prof_begin(1, wgrad_alg_flops(k.p), st, tag);
     hipLaunchKernelGGL(kern, dim3(k.ngroups * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
@@ -345,8 +387,11 @@ int launch_wgrad(WgradP p, hipStream_t st)
     const size_t need = (size_t)nP * k.pstride * sizeof(float);
     ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
     int rc;
-    if (p.TY == 3 && p.TX == 3 && p.stride == 1) rc = launch_wgrad_t<3, 3, 1>(k, st);
-    else if (p.TY == 2 && p.TX == 2 && p.stride == 2) rc = launch_wgrad_t<2, 2, 2>(k, st);
+    const int mode = get_math_mode();
+    if (p.TY == 3 && p.TX == 3 && p.stride == 1)
+        rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_t<3, 3, 1, 1>(k, st);
+    else if (p.TY == 2 && p.TX == 2 && p.stride == 2)
+        rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_t<2, 2, 2, 1>(k, st);
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
     if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");

@@ -46,6 +46,13 @@ typedef struct unet_config {
 const char *unet_last_error(void);
 int unet_abi_version(void);
 
+/* Arithmetic of the dense contractions (process-wide): 0 = exact fp32 MFMA (default; fmaf-chain numerics),
+ * 1 = bf16x3: fp32 operands split into two bf16 terms, three bf16 MFMAs per product, fp32 accumulation
+ *     (~16-bit products; logits stay within ~1e-5 of fp32), 2 = bf16 operands, fp32 accumulation and storage
+ *     (BASELINE config #3).  Tensors in HBM stay fp32 in every mode.  Also settable with UNET_MATH.           */
+int unet_set_math(int mode);
+int unet_get_math(void);
+
 /* ---- handle ------------------------------------------------------------------------------
  * replaces: Unet.__init__ bookkeeping that is not parameters (network.py:20-58).            */
 int unet_create(unet_handle **out, const unet_config *cfg);
