@@ -41,6 +41,18 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 //    "full" padding of the dgrad correlation)
 //   kd order: source-major, then tap, then channel — the weight packers produce exactly this.
 // ---------------------------------------------------------------------------------------------
+// exact unsigned division by a launch-time constant: q = (n * mul) >> shift for n < 2^31 (64-bit product)
+struct FastDiv { unsigned long long mul; int shift; };
+static inline FastDiv make_fastdiv(unsigned d)
+{
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    FastDiv f;
+    f.shift = 32 + s;
+    f.mul = ((1ull << f.shift) + d - 1) / d;
+    return f;
+}
+
 struct GSrc {
     const float *p;
     int H, W, C;      // tensor extent per image and channel pitch
@@ -69,6 +81,7 @@ struct IgemmP {
     const float *add;    // same geometry as dst: v += add
     const float *zeros;
     int mtiles, ntiles;
+    FastDiv d_ohw, d_ow;   // set by launch_igemm: division by OH*OW and by OW (pixel index -> image, row, column)
 };
 int launch_igemm(IgemmP p, hipStream_t st);
 int get_math_mode();

@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
         for (int i = 0; i < RA; ++i) {
             int m = m0 + srow + 32 * i;
             m = m < p.M ? m : p.M - 1;
-            const int img = m / ohw;
+            const int img = fdiv(m, p.d_ohw);
             const int rem = m - img * ohw;
-            const int oy = rem / p.OW;
+            const int oy = fdiv(rem, p.d_ow);
             const int ox = rem - oy * p.OW;
             const int iy = (oy + p.oy0) * p.stride - g.pad;
             const int ix = (ox + p.ox0) * p.stride - g.pad;
@@ -243,6 +243,8 @@ int launch_igemm(IgemmP p, hipStream_t st)
         ARG_CHECK((size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C < 0x7FFFFFFFull, "igemm: source exceeds 31-bit element offsets");
     p.zeros = zero_page();
     if (!p.zeros) return -2;
+    p.d_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
+    p.d_ow = make_fastdiv((unsigned)p.OW);
     if (g_math_mode == 1) return launch_igemmx(p, pad, 3, st);
     if (g_math_mode == 2) return launch_igemmx(p, pad, 1, st);
     static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();

@@ -17,6 +17,7 @@
 // LDS rows are 64 B (16 floats of K); the 16-B chunk index is XOR-swizzled with (row>>2)&3 on the
 // SOURCE address of the LDS-DMA and on the fragment read -> conflict-free ds_read_b128.
 #include "common.hpp"
+#include "igemm_epilogue.hpp"
 #include <cstdio>
 
 namespace unet {
@@ -89,9 +90,9 @@ __global__ __launch_bounds__(256, 2) void igemm2_f32_kernel(const IgemmP p)
         for (int i = 0; i < RA; ++i) {
             int m = m0 + srow + 64 * i;
             m = m < p.M ? m : p.M - 1;
-            const int img = m / ohw;
+            const int img = fdiv(m, p.d_ohw);
             const int rem = m - img * ohw;
-            const int oy = rem / p.OW;
+            const int oy = fdiv(rem, p.d_ow);
             const int ox = rem - oy * p.OW;
             const int iy = (oy + p.oy0) * p.stride - g.pad;
             const int ix = (ox + p.ox0) * p.stride - g.pad;
@@ -208,9 +209,9 @@ __global__ __launch_bounds__(256, 2) void igemm2_f32_kernel(const IgemmP p)
             off = (unsigned)m * (unsigned)p.DC;
         } else {
             const int ohw = p.OH * p.OW;
-            const int img = m / ohw;
+            const int img = fdiv(m, p.d_ohw);
             const int rem = m - img * ohw;
-            const int oy = rem / p.OW;
+            const int oy = fdiv(rem, p.d_ow);
             const int ox = rem - oy * p.OW;
             off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
         }

@@ -4,6 +4,8 @@
 
 namespace unet {
 
+__device__ __forceinline__ int fdiv(int n, const FastDiv &f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift); }
+
 // ---- epilogue: bias / add / ReLU / mask / store with 16-byte accesses.
 // The MFMA accumulator layout gives a lane one column and 16 rows, i.e. dword stores (64 per lane; measured
 // ~4 us of store issue per workgroup, 18 % of a short-K layer).  Each wave therefore transposes its 32x32
@@ -28,9 +30,9 @@ __device__ __forceinline__ void igemm_rowoff_entry(const IgemmP &p, int m0, int 
         off = (unsigned)m * (unsigned)p.DC;
     } else {
         const int ohw = p.OH * p.OW;
-        const int img = m / ohw;
+        const int img = fdiv(m, p.d_ohw);
         const int rem = m - img * ohw;
-        const int oy = rem / p.OW;
+        const int oy = fdiv(rem, p.d_ow);
         const int ox = rem - oy * p.OW;
         if (p.scatter == 1) off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
         else if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;

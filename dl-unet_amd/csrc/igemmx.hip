@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256, 2) void igemmx_kernel(const IgemmP p)
         for (int i = 0; i < RA; ++i) {
             int m = m0 + srow + 32 * i;
             m = m < p.M ? m : p.M - 1;
-            const int img = m / ohw;
+            const int img = fdiv(m, p.d_ohw);
             const int rem = m - img * ohw;
-            const int oy = rem / p.OW;
+            const int oy = fdiv(rem, p.d_ow);
             const int ox = rem - oy * p.OW;
             const int iy = (oy + p.oy0) * p.stride - g.pad;
             const int ix = (ox + p.ox0) * p.stride - g.pad;
