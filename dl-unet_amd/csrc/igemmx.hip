@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256, 2) void igemmx_kernel(const IgemmP p)
         }
         toff = 0;
     };
-    f32x4 ra[RA], rb[RB];
-    auto load_regs = [&]() {
+    // two register sets: global loads run TWO K steps ahead of their conversion (the MFMA phase of one step
+    // is shorter than an L2/HBM round trip on the bf16 matrix cores)
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+    auto load_regs = [&](f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const float *g = sp + (a_off[i] + toff + kc);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void igemmx_kernel(const IgemmP p)
             *(bf16x4 *)(rowbase + wr_lo) = lo;
         }
     };
-    auto write_lds = [&](int buf) {
+    auto write_lds = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
         unsigned char *abase = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < RA; ++i) put(abase + i * (32 * 128), ra[i]);
@@ -146,14 +148,13 @@ __global__ __launch_bounds__(256, 2) void igemmx_kernel(const IgemmP p)
 
     const int nk = p.Kd >> 5;
     setup_source(0);
-    load_regs();
-    write_lds(0);
+    load_regs(ra0, rb0);                     // stage 0
     advance();
+    if (nk > 1) { load_regs(ra1, rb1); advance(); }      // stage 1
+    write_lds(0, ra0, rb0);
     __syncthreads();
 
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) { load_regs(); advance(); }
+    auto compute = [&](int cur) {
         const unsigned char *sb = smem + cur * STAGE;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {                       // two K=16 MFMA steps per 32-wide K slice
@@ -180,9 +181,21 @@ __global__ __launch_bounds__(256, 2) void igemmx_kernel(const IgemmP p)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
                 }
         }
-        if (ks + 1 < nk) write_lds(cur ^ 1);
+    };
+    // step ks: stage ks is in LDS buffer ks&1, stage ks+1 is in the register set (ks+1)&1; issue stage ks+2 into
+    // the set ks&1 (free since stage ks was written out), compute, then convert stage ks+1 into the other buffer
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+        if (ks + 2 < nk) { load_regs(ra0, rb0); advance(); }
+        compute(0);
+        write_lds(1, ra1, rb1);
+        __syncthreads();
+        if (ks + 3 < nk) { load_regs(ra1, rb1); advance(); }
+        compute(1);
+        if (ks + 2 < nk) write_lds(0, ra0, rb0);
         __syncthreads();
     }
+    if (ks < nk) { compute(0); __syncthreads(); }
     igemm_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
 }
 
