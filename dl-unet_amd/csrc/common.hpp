@@ -30,6 +30,18 @@ const float *zero_page();          // 4 KiB of device zeros on the current devic
 void prof_begin(int family, double flops, hipStream_t st, const char *tag = nullptr);
 void prof_end(hipStream_t st);
 
+// raise a kernel's dynamic-LDS limit once per (kernel, device)
+static inline int ensure_dynamic_lds(const void *kern, int bytes, bool (&done)[64])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("bad device"); return -2; }
+    if (!done[dev]) {
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done[dev] = true;
+    }
+    return 0;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -197,12 +197,9 @@ template <int BM, int BN, bool PAD>
 static int launch_cfg(const IgemmP &p, hipStream_t st)
 {
     constexpr int LDS = 2 * (BM + BN) * 128;
-    static bool attr_done = false;
+    static bool attr_done[64] = {false};
     auto kern = igemm_f32_kernel<BM, BN, PAD>;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, attr_done)) return rc_;
     IgemmP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Nn, BN);

@@ -205,12 +205,9 @@ template <int BM, int BN, bool PAD, int NSPLIT>
 static int launch_cfgx(const IgemmP &p, hipStream_t st)
 {
     constexpr int LDS = 2 * (BM + BN) * 128;
-    static bool attr_done = false;
+    static bool attr_done[64] = {false};
     auto kern = igemmx_kernel<BM, BN, PAD, NSPLIT>;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, attr_done)) return rc_;
     IgemmP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Nn, BN);

@@ -355,12 +355,9 @@ template <int TY, int TX, int S, int NSPLIT>
 static int launch_wgrad_t(const WgradK &k, hipStream_t st)
 {
     using G = WgradGeom<TY, TX, S>;
-    static bool attr_done = false;
+    static bool attr_done[64] = {false};
     auto kern = wgrad_f32_kernel<TY, TX, S, NSPLIT>;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        attr_done = true;
-    }
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, G::LDS, attr_done)) return rc_;
     char tag[96];
     snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d;split%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, NSPLIT, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
              k.p.ywin1 - k.p.ywin0, k.nparts, k.pw, k.rows_per_chunk, k.ngroups);

