@@ -112,6 +112,7 @@ struct WgradP {
     int Ci, Cj;                        // multiples of 64
     float *out; long si, sj, st;       // final gradient tensor strides (elements)
     float *db;                         // optional fused bias gradient db[yc0 + j] = sum Y (needs the full window)
+    int db_on_x;                       // 1: db[xc0 + i] = sum X instead (up-conv: X is dOut, stride == taps so every X pixel is staged once)
     float *slab; size_t slab_bytes;    // scratch for partials
     const float *zeros;
 };

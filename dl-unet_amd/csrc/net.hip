@@ -208,7 +208,7 @@ static WgradP conv_wgrad_desc(const float *X, int XH, int XC, int xpad, const fl
 }
 
 static WgradP upconv_wgrad_desc(const float *x, int H, int Ci, const float *dy, int Co, int B, float *dw,
-                                float *slab, size_t slab_bytes)
+                                float *slab, size_t slab_bytes, float *db = nullptr)
 {
     WgradP p{};
     p.X = dy; p.XH = 2 * H; p.XW = 2 * H; p.XC = Co; p.xc0 = 0; p.xpad = 0;
@@ -218,6 +218,7 @@ static WgradP upconv_wgrad_desc(const float *x, int H, int Ci, const float *dy, 
     p.Ci = Co; p.Cj = Ci;
     p.out = dw; p.si = 4; p.sj = (long)Co * 4; p.st = 1;
     p.slab = slab; p.slab_bytes = slab_bytes;
+    p.db = db; p.db_on_x = db ? 1 : 0;        // db[co] = sum dOut: X is dOut here
     return p;
 }
 
@@ -577,9 +578,8 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             d.dst = dzin; d.DH = hin; d.DW = hin; d.DC = ch[l + 1];
             d.mask = uin;
             if ((rc = launch_igemm(d, st))) return rc;
-            WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes);
+            WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes, GRAD(2 * ul + 1));
             if ((rc = launch_wgrad(w, st))) return rc;
-            if ((rc = bias_grad(WS(pl.g_u[l]), (size_t)B * pl.eu[l] * pl.eu[l], ch[l], GRAD(2 * ul + 1), WS(pl.small), st))) return rc;
         }
         return 0;
     }
@@ -746,10 +746,9 @@ int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_i
         if ((rc = launch_igemm(d, st))) return rc;
     }
     if (dw) {
-        WgradP w = upconv_wgrad_desc((const float *)x, H, Ci, (const float *)dy, Co, B, (float *)dw, slab, slab_bytes);
+        WgradP w = upconv_wgrad_desc((const float *)x, H, Ci, (const float *)dy, Co, B, (float *)dw, slab, slab_bytes, (float *)db);
         if ((rc = launch_wgrad(w, st))) return rc;
-    }
-    if (db && (rc = bias_grad((const float *)dy, (size_t)B * 4 * H * W, Co, (float *)db, small, st))) return rc;
+    } else if (db && (rc = bias_grad((const float *)dy, (size_t)B * 4 * H * W, Co, (float *)db, small, st))) return rc;
     return 0;
 }
 

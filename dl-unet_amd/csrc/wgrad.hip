@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // fused bias gradient: the i-tile-0 workgroups also sum their Y strip over pixels (db[j] = sum dz)
-    const bool do_bias = p.db != nullptr && it == 0;
+    const bool do_bias = p.db != nullptr && !p.db_on_x && it == 0;
+    const bool do_xbias = p.db != nullptr && p.db_on_x && jt == 0;
     float bsum = 0.f;
     const int bch = tid & 63, bpg = tid >> 6;
 
@@ -143,6 +144,12 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
             if (do_bias) {
                 const float *yb_ = (const float *)(ys + cur * G::YBUF) + bch;
                 for (int px = bpg; px < pwv; px += 4) bsum += yb_[px * 64];
+            }
+            if (do_xbias) {                  // the S rows of X first used by this step, 'S * pwv' pixels each
+                for (int r = 0; r < S; ++r) {
+                    const float *xb_ = (const float *)(xs + ((xr0 + TY - S + r) & (G::RING - 1)) * G::XSLOT) + bch;
+                    for (int px = bpg; px < S * pwv; px += 4) bsum += xb_[px * 64];
+                }
             }
             const unsigned char *yrow = ys + cur * G::YBUF + b_lane;
             if constexpr (NSPLIT == 0) {
@@ -206,11 +213,11 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
 
     // accumulated tile -> slab of this group (+ [Cj] bias partials behind the T*Ci*Cj weight partials)
     float *slab = p.slab + (size_t)grp * k.pstride;
-    if (do_bias) {
+    if (do_bias || do_xbias) {
         float *red = (float *)smem;             // all LDS reads of the loop are behind its last barrier
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 64) slab[(size_t)T * p.Ci * p.Cj + jt * 64 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+        if (tid < 64) slab[(size_t)T * p.Ci * p.Cj + (do_xbias ? it : jt) * 64 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
     }
     // register-order layout [tile][wave][t][r/4][lane][r%4]: one 16-byte store per lane and (t, r/4), 1 KiB per
     // wave instruction (the 144 dword stores this replaces were store-issue bound); the reduce kernel decodes it.
@@ -226,10 +233,10 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
 // Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
 // even when the output is tiny (64x64x9) and the partition count is in the thousands.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, size_t pstride, int T, int Ci, int Cj,
-                                                           float *__restrict__ out, long si, long sj, long st, float *__restrict__ db)
+                                                           float *__restrict__ out, long si, long sj, long st, float *__restrict__ db, int ndb)
 {
     const size_t nw = (size_t)T * Ci * Cj;
-    const size_t total = nw + (db ? (size_t)Cj : 0);
+    const size_t total = nw + (db ? (size_t)ndb : 0);
     const int lane_e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     __shared__ float red[256];
     for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
@@ -299,7 +306,7 @@ static void decompose(const WgradP &p, WgradK &k)
             k.nchunks = cdiv(wy, k.rows_per_chunk);
             k.nparts = (int)(per_chunk * k.nchunks);
             k.ngroups = itc->second.second;
-            k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + p.Cj, 64);
+            k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + (p.Ci > p.Cj ? p.Ci : p.Cj), 64);
             return;
         }
     }
@@ -331,7 +338,7 @@ static void decompose(const WgradP &p, WgradK &k)
         std::lock_guard<std::mutex> lk(mu);
         cache[key] = std::make_pair(best_r, best_g);
     }
-    k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + p.Cj, 64);
+    k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + (p.Ci > p.Cj ? p.Ci : p.Cj), 64);
 }
 
 size_t wgrad_slab_need(const WgradP &p)
@@ -392,11 +399,13 @@ int launch_wgrad(WgradP p, hipStream_t st)
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
     if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");
-    const size_t total = (size_t)T * p.Ci * p.Cj + (p.db ? p.Cj : 0);
+    if (p.db && p.db_on_x) ARG_CHECK(p.stride == p.TY && p.stride == p.TX && p.xpad == 0, "wgrad: bias-on-X needs stride == taps (every X pixel staged exactly once)");
+    const int ndb = p.db ? (p.db_on_x ? p.Ci : p.Cj) : 0;
+    const size_t total = (size_t)T * p.Ci * p.Cj + ndb;
     size_t blocks = (total + 63) / 64;
     if (blocks > 16384) blocks = 16384;
     prof_begin(2, 0.0, st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st, p.db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st, p.db, ndb);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
