@@ -25,6 +25,8 @@ namespace unet {
 
 int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st);
 int launch_igemmx(const IgemmP &p, bool pad, int nsplit, hipStream_t st);
+int launch_igemmh(const IgemmP &p, hipStream_t st);
+bool igemmh_applicable(const IgemmP &p);
 
 // 0 = exact fp32 MFMA (default), 1 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores), 2 = bf16 compute
 static int g_math_mode = [] { const char *e = getenv("UNET_MATH"); return e ? atoi(e) : 0; }();
@@ -244,6 +246,9 @@ int launch_igemm(IgemmP p, hipStream_t st)
     p.d_ow = make_fastdiv((unsigned)p.OW);
     if (g_math_mode == 1) return launch_igemmx(p, pad, 3, st);
     if (g_math_mode == 2) return launch_igemmx(p, pad, 1, st);
+    static const int halo = [] { const char *e = getenv("UNET_HALO"); return e ? atoi(e) : 0; }();   // opt-in: measured 0-15 % slower in fp32
+    ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemm: destination exceeds 31-bit element offsets");
+    if (halo && igemmh_applicable(p)) return launch_igemmh(p, st);
     static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();
     if (gen == 2 && p.scatter != 2 && p.rw1 <= p.rw0) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
     if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true>(p, st) : launch_cfg<128, 128, false>(p, st);
