@@ -92,10 +92,15 @@ struct IgemmP {
     const float *mask;   // same geometry as dst: v = mask>0 ? v : 0  (ReLU backward)
     const float *add;    // same geometry as dst: v += add
     const float *zeros;
+    const float *wino_u;   // math mode 3: Winograd-transformed filters of this launch (wino.hip), else null
     int mtiles, ntiles;
     FastDiv d_ohw, d_ow;   // set by launch_igemm: division by OH*OW and by OW (pixel index -> image, row, column)
 };
 int launch_igemm(IgemmP p, hipStream_t st);
+// Winograd F(2x2,3x3) path (wino.hip): filter transform into U (wino_u_floats(channels, Nn) floats) and applicability
+bool wino_applicable(const IgemmP &p);
+size_t wino_u_floats(int Kc, int Nn);
+int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *U, hipStream_t st);
 int get_math_mode();
 void set_math_mode(int m);
 

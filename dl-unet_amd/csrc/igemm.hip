@@ -27,8 +27,10 @@ int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st);
 int launch_igemmx(const IgemmP &p, bool pad, int nsplit, hipStream_t st);
 int launch_igemmh(const IgemmP &p, hipStream_t st);
 bool igemmh_applicable(const IgemmP &p);
+int launch_wino(const IgemmP &p, const float *U, hipStream_t st);
 
-// 0 = exact fp32 MFMA (default), 1 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores), 2 = bf16 compute
+// 0 = exact fp32 MFMA (default), 1 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores), 2 = bf16 compute,
+// 3 = fp32 with Winograd F(2x2,3x3) for the stride-1 3x3 layers (everything else as mode 0)
 static int g_math_mode = [] { const char *e = getenv("UNET_MATH"); return e ? atoi(e) : 0; }();
 int get_math_mode() { return g_math_mode; }
 void set_math_mode(int m) { g_math_mode = m; }
@@ -244,6 +246,10 @@ int launch_igemm(IgemmP p, hipStream_t st)
     if (!p.zeros) return -2;
     p.d_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
     p.d_ow = make_fastdiv((unsigned)p.OW);
+    if (g_math_mode == 3 && p.wino_u && wino_applicable(p)) {
+        ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemm: destination exceeds 31-bit element offsets");
+        return launch_wino(p, p.wino_u, st);
+    }
     if (g_math_mode == 1) return launch_igemmx(p, pad, 3, st);
     if (g_math_mode == 2) return launch_igemmx(p, pad, 1, st);
     static const int halo = [] { const char *e = getenv("UNET_HALO"); return e ? atoi(e) : 0; }();   // opt-in: measured 0-15 % slower in fp32

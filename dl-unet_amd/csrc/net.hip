@@ -54,6 +54,7 @@ struct Plan {
     int ein[5], ea1[5], ea2[5], et[4], eu[4], ed1[4], ed2[4], pad[4];
     size_t a1[5], a2[5], t[4], u[4], d1[4], d2[4];
     size_t wt_fwd[UNET_N_LAYERS], wt_bwd[UNET_N_LAYERS];
+    size_t wu_fwd[UNET_N_LAYERS], wu_bwd[UNET_N_LAYERS];     // Winograd-transformed filters (math mode 3), 16/9 of the 3x3 layers
     size_t g_a1[5], g_a2[5], g_t[4], g_ts[4], g_u[4], g_d1[4], g_d2[4];
     size_t slab = 0, slab_bytes = 0, small = 0, small_bytes = 0, xin = 0;
     size_t total = 0;
@@ -120,6 +121,23 @@ static size_t layer_numel(int base, int layer, bool bias)
     return bias ? (size_t)co : (size_t)ci * co * k * k;
 }
 
+// floats of the Winograd U matrix of a layer (0 for the layers wino.hip does not serve: conv11c, up-convs, head)
+static size_t layer_wino_floats(int base, int layer)
+{
+    if (layer == C11C || layer == UP4 || layer == UP3 || layer == UP2 || layer == UP1 || layer == FINAL) return 0;
+    return layer_numel(base, layer, false) / 9 * 16;
+}
+
+// math mode 3: transform this launch's packed filters into `wu` and route the launch to wino.hip
+static int with_wino(IgemmP &p, float *wu, hipStream_t st)
+{
+    if (get_math_mode() != 3 || !wu || !wino_applicable(p)) return 0;
+    int rc = wino_transform(p.wt, p.ldw ? p.ldw : p.Kd, p.Nn, p.src[0].nch, p.nsrc > 1 ? p.src[1].nch : 0, wu, st);
+    if (rc) return rc;
+    p.wino_u = wu;
+    return 0;
+}
+
 static int check_size(int S)
 {
     if (S < 60 + 16 * 8 || (S - 60) % 16 != 0 || ((S - 60) / 16) % 2 != 0) {
@@ -152,27 +170,30 @@ static IgemmP conv_fwd_desc(const float *x1, int H1, int W1, int C1, int pad1, c
 // window), launch 2 = skip source over the window only, accumulating in place (+ReLU).  Same math, same
 // K order per source; the two partial sums are added in fp32.
 static int conv_fwd_launch(const float *x1, int H1, int C1, int pad1, const float *x2, int C2, int B, int H,
-                           const float *wt, const float *bias, int K, int relu, float *y, hipStream_t st)
+                           const float *wt, const float *bias, int K, int relu, float *y, hipStream_t st, float *wu = nullptr)
 {
     const int Ho = H - 2;
+    int rc;
     int w0 = pad1 - 2; if (w0 < 0) w0 = 0;
     int w1 = pad1 + H1; if (w1 > Ho) w1 = Ho;
     const bool split = x2 && pad1 > 0 && (double)(w1 - w0) * (w1 - w0) < 0.85 * (double)Ho * Ho;
     if (!split) {
         IgemmP p = conv_fwd_desc(x1, H1, H1, C1, pad1, x2, x2 ? C2 : 0, B, H, H, wt, bias, K, relu, y);
+        if ((rc = with_wino(p, wu, st))) return rc;
         return launch_igemm(p, st);
     }
     const int ldw = 9 * (C1 + C2);
     IgemmP a = conv_fwd_desc(x2, H, H, C2, 0, nullptr, 0, B, H, H, wt + 9 * C1, bias, K, relu, y);
     a.ldw = ldw;
     if (relu) { a.rw0 = w0; a.rw1 = w1; }
-    int rc = launch_igemm(a, st);
-    if (rc) return rc;
+    if ((rc = with_wino(a, wu, st))) return rc;
+    if ((rc = launch_igemm(a, st))) return rc;
     IgemmP b = conv_fwd_desc(x1, H1, H1, C1, pad1, nullptr, 0, B, H, H, wt, nullptr, K, relu, y);
     b.ldw = ldw;
     b.OH = b.OW = w1 - w0; b.M = B * b.OH * b.OW; b.oy0 = b.ox0 = w0;
     b.scatter = 2; b.dwy0 = b.dwx0 = w0; b.DH = b.DW = Ho;
     b.add = y;
+    if ((rc = with_wino(b, wu ? wu + wino_u_floats(C2, K) : nullptr, st))) return rc;
     return launch_igemm(b, st);
 }
 
@@ -253,9 +274,11 @@ static int make_plan(Plan &pl, int base, int B, int S, int training)
         pl.d1[l] = take(sq(pl.ed1[l], pl.ch[l])); pl.d2[l] = take(sq(pl.ed2[l], pl.ch[l]));
     }
     for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wt_fwd[i] = take(layer_numel(base, i, false));
+    for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wu_fwd[i] = take(layer_wino_floats(base, i));
     if (training) {
         pl.xin = take((size_t)B * S * S);
         for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wt_bwd[i] = take(layer_numel(base, i, false));
+        for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wu_bwd[i] = take(layer_wino_floats(base, i));
         for (int l = 0; l < 5; ++l) { pl.g_a1[l] = take(sq(pl.ea1[l], pl.ch[l])); pl.g_a2[l] = take(sq(pl.ea2[l], pl.ch[l])); }
         for (int l = 0; l < 4; ++l) {
             pl.g_t[l] = take(sq(pl.et[l], pl.ch[l])); pl.g_ts[l] = take(sq(pl.et[l], pl.ch[l]));
@@ -303,7 +326,7 @@ int unet_abi_version(void) { return 1; }
 
 int unet_set_math(int mode)
 {
-    ARG_CHECK(mode >= 0 && mode <= 2, "unet_set_math: mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (bf16)");
+    ARG_CHECK(mode >= 0 && mode <= 3, "unet_set_math: mode must be 0 (fp32 MFMA), 1 (bf16x3), 2 (bf16) or 3 (fp32 Winograd)");
     set_math_mode(mode);
     return 0;
 }
@@ -406,10 +429,12 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
         if (l > 0) {
             IgemmP p = conv_fwd_desc(WS(pl.t[l - 1]), pl.ein[l], pl.ein[l], ch[l - 1], 0, nullptr, 0, B, pl.ein[l], pl.ein[l],
                                      WS(pl.wt_fwd[2 * l]), PARAM(2 * (2 * l) + 1), ch[l], 1, WS(pl.a1[l]));
+            if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l]), st))) return rc;
             if ((rc = launch_igemm(p, st))) return rc;
         }
         IgemmP p = conv_fwd_desc(WS(pl.a1[l]), pl.ea1[l], pl.ea1[l], ch[l], 0, nullptr, 0, B, pl.ea1[l], pl.ea1[l],
                                  WS(pl.wt_fwd[2 * l + 1]), PARAM(2 * (2 * l + 1) + 1), ch[l], 1, WS(pl.a2[l]));
+        if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l + 1]), st))) return rc;
         if ((rc = launch_igemm(p, st))) return rc;
         if (l < 4 && (rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
     }
@@ -426,9 +451,10 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
         u.bias = PARAM(2 * UP_L[l] + 1);
         if ((rc = launch_igemm(u, st))) return rc;
         if ((rc = conv_fwd_launch(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l],
-                                  WS(pl.wt_fwd[C1E_L[l]]), PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st))) return rc;
+                                  WS(pl.wt_fwd[C1E_L[l]]), PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st, WS(pl.wu_fwd[C1E_L[l]])))) return rc;
         IgemmP c2 = conv_fwd_desc(WS(pl.d1[l]), pl.ed1[l], pl.ed1[l], ch[l], 0, nullptr, 0, B, pl.ed1[l], pl.ed1[l],
                                   WS(pl.wt_fwd[C2E_L[l]]), PARAM(2 * C2E_L[l] + 1), ch[l], 1, WS(pl.d2[l]));
+        if ((rc = with_wino(c2, WS(pl.wu_fwd[C2E_L[l]]), st))) return rc;
         if ((rc = launch_igemm(c2, st))) return rc;
         dsrc = WS(pl.d2[l]);
     }
@@ -510,6 +536,7 @@ static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const 
     if (dx) {
         if ((rc = pack_conv_dgrad(PARAM(2 * layer), WS(pl.wt_bwd[layer]), K, C, st))) return rc;
         IgemmP d = conv_dgrad_desc(dz, Ho, Ho, K, B, XH, 0, WS(pl.wt_bwd[layer]), C, dx, mask, add);
+        if ((rc = with_wino(d, WS(pl.wu_bwd[layer]), st))) return rc;
         if ((rc = launch_igemm(d, st))) return rc;
     }
     WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes, GRAD(2 * layer + 1));
@@ -550,9 +577,11 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
         {
             IgemmP ds = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.et[l], pl.pad[l],
                                         WS(pl.wt_bwd[lay]), ch[l], WS(pl.g_ts[l]), nullptr, nullptr);
+            if ((rc = with_wino(ds, WS(pl.wu_bwd[lay]), st))) return rc;
             if ((rc = launch_igemm(ds, st))) return rc;
             IgemmP du = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.eu[l], 0,
                                         WS(pl.wt_bwd[lay]) + (size_t)ch[l] * 9 * ch[l], ch[l], WS(pl.g_u[l]), nullptr, nullptr);
+            if ((rc = with_wino(du, WS(pl.wu_bwd[lay]) + wino_u_floats(ch[l], ch[l]), st))) return rc;
             if ((rc = launch_igemm(du, st))) return rc;
         }
         {
@@ -631,7 +660,7 @@ static size_t conv_bwd_slab_bound(int B, int H, int C, int K)
 }
 
 // ---- per-op entry points (unit tests) --------------------------------------------------------------
-size_t unet_conv3x3_scratch_bytes(int C, int K) { return align_up((size_t)K * C * 9 * sizeof(float), 256); }
+size_t unet_conv3x3_scratch_bytes(int C, int K) { return align_up((size_t)K * C * 9 * sizeof(float), 256) + align_up((size_t)K * C * 16 * sizeof(float), 256); }
 
 int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2, int B, int H, int W,
                      const void *w_oihw, const void *bias, int K, int relu, void *y, void *scratch, void *stream)
@@ -642,14 +671,15 @@ int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
     int rc = pack_conv_fwd((const float *)w_oihw, (float *)scratch, K, C1, x2 ? C2 : 0, st);
     if (rc) return rc;
     ARG_CHECK(H == W && H1 == W1, "conv3x3_fwd: square tiles only");
+    float *wu = (float *)((char *)scratch + align_up((size_t)K * (C1 + (x2 ? C2 : 0)) * 9 * sizeof(float), 256));
     return conv_fwd_launch((const float *)x1, H1, C1, pad1, (const float *)x2, x2 ? C2 : 0, B, H, (const float *)scratch,
-                           (const float *)bias, K, relu, (float *)y, st);
+                           (const float *)bias, K, relu, (float *)y, st, wu);
 }
 
 size_t unet_conv3x3_bwd_scratch_bytes(int B, int H, int W, int C, int K)
 {
     return align_up((size_t)K * C * 9 * sizeof(float), 256) + conv_bwd_slab_bound(B, H, C, K) +
-           align_up(bias_grad_scratch_bytes((size_t)B * (H - 2) * (W - 2), K), 256);
+           align_up(bias_grad_scratch_bytes((size_t)B * (H - 2) * (W - 2), K), 256) + align_up((size_t)K * C * 16 * sizeof(float), 256);
 }
 
 int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2, int B, int H, int W,
@@ -666,15 +696,18 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
     const size_t slab_bytes = conv_bwd_slab_bound(B, H, C, K);
     float *slab = (float *)((char *)scratch + wt_bytes);
     float *small = (float *)((char *)scratch + wt_bytes + slab_bytes);
+    float *wu = (float *)((char *)scratch + wt_bytes + slab_bytes + align_up(bias_grad_scratch_bytes((size_t)B * Ho * Ho, K), 256));
     int rc;
     if (dx1 || dx2) {
         if ((rc = pack_conv_dgrad((const float *)w_oihw, wt, K, C, st))) return rc;
         if (dx1) {
             IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H1, pad1, wt, C1, (float *)dx1, (const float *)mask1, (const float *)add1);
+            if ((rc = with_wino(d, wu, st))) return rc;
             if ((rc = launch_igemm(d, st))) return rc;
         }
         if (dx2 && x2) {
             IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H, 0, wt + (size_t)C1 * 9 * K, C2, (float *)dx2, (const float *)mask2, nullptr);
+            if ((rc = with_wino(d, wu + wino_u_floats(K, C1), st))) return rc;
             if ((rc = launch_igemm(d, st))) return rc;
         }
     }

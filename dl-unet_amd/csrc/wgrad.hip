@@ -292,7 +292,7 @@ static void decompose(const WgradP &p, WgradK &k)
     // Choose rows-per-chunk r and ngroups to minimise  rounds(ngroups*ntile / resident slots) x ceil(nparts/ngroups) x r
     // (all workgroups of a launch do the same per-row work), preferring fewer groups (slab traffic) on ties.
     const int ntile = k.ntile_i * k.ntile_j;
-    const int slots = 256 * ((p.TY == 3 && get_math_mode() == 0) ? 3 : 2);
+    const int slots = 256 * ((p.TY == 3 && (get_math_mode() == 0 || get_math_mode() == 3)) ? 3 : 2);
     const long per_chunk = (long)p.NB * k.nstrips;
     // the search is a few million cheap iterations: memoise per shape (hot calls hit the cache)
     static std::mutex mu;
@@ -391,7 +391,7 @@ int launch_wgrad(WgradP p, hipStream_t st)
     const size_t need = (size_t)nP * k.pstride * sizeof(float);
     ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
     int rc;
-    const int mode = get_math_mode();
+    const int mode = get_math_mode() == 3 ? 0 : get_math_mode();     // mode 3 (Winograd) only changes the igemm side
     if (p.TY == 3 && p.TX == 3 && p.stride == 1)
         rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_t<3, 3, 1, 1>(k, st);
     else if (p.TY == 2 && p.TX == 2 && p.stride == 2)

@@ -52,8 +52,16 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
 
 
+@pytest.fixture(params=[0, 3], ids=["direct", "winograd"])
+def conv_mode(hip, request):
+    """The 3x3 layers have two fp32 evaluations: the direct fmaf chain (math mode 0) and Winograd F(2x2,3x3) (mode 3)."""
+    hip.check(hip.lib().unet_set_math(request.param), "set_math")
+    yield request.param
+    hip.check(hip.lib().unet_set_math(0), "set_math")
+
+
 @pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32)])
-def test_conv3x3_fwd(hip, B, H, C, K):
+def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1); w = rnd(K, C, 3, 3, seed=2, scale=0.05); b = rnd(K, seed=3)
     ref = F.relu(F.conv2d(x, w, b))
@@ -65,7 +73,7 @@ def test_conv3x3_fwd(hip, B, H, C, K):
 
 
 @pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128)])
-def test_conv3x3_fwd_virtual_concat(hip, B, Hs, pad, C1, C2, K):
+def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
     keep = Keep()
     """crop_and_concat (network.py:108-127) is never materialised: the conv reads two sources."""
     H = Hs + 2 * pad
@@ -83,7 +91,7 @@ def test_conv3x3_fwd_virtual_concat(hip, B, Hs, pad, C1, C2, K):
 
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True),
                                                       (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False)])
-def test_conv3x3_bwd(hip, B, H, C, K, use_mask, use_add):
+def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1).requires_grad_(True)
     w = rnd(K, C, 3, 3, seed=2, scale=0.05).requires_grad_(True)
@@ -108,7 +116,7 @@ def test_conv3x3_bwd(hip, B, H, C, K, use_mask, use_add):
 
 
 @pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 8, 0, 64, 64)])
-def test_conv3x3_bwd_virtual_concat(hip, B, Hs, pad, C, K):
+def test_conv3x3_bwd_virtual_concat(hip, conv_mode, B, Hs, pad, C, K):
     keep = Keep()
     H = Hs + 2 * pad
     a = rnd(B, C, Hs, Hs, seed=1).requires_grad_(True); u = rnd(B, C, H, H, seed=2).requires_grad_(True)
