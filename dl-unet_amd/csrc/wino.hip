@@ -28,6 +28,7 @@
 #include "igemm_epilogue.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace unet {
 
@@ -46,8 +47,6 @@ struct WinoP {
     FastDiv d_tpi, d_tx;
 };
 
-constexpr int WINO_STAGE = 65536;      // 32 KiB patches + 32 KiB U
-constexpr int WINO_LDS = 2 * WINO_STAGE;
 
 // --------------------------------------------------------------------------------------------------------
 // U = G g G^T for every (n, c), written in the order the main kernel stages and reads it:
@@ -106,7 +105,40 @@ int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *
 }
 
 // --------------------------------------------------------------------------------------------------------
-template <int DBG>
+// LDS: [3 x patch stage 18 KiB][3 x U block 32 KiB] = 150 KiB, two independent 3-deep rings.
+//   patch stage  [qy 4][par 2][idx 72][slot 2][16 B]:  idx < 64: pixel (qy, qx = par) of tile idx; idx = 64 + j: pixel
+//                (qy, qx = 2 + par) of "tail" j; slot = half ^ ((idx>>3)&1) holds channels 4*half..+3 of the step.
+//                The two halves of a pixel are adjacent lanes of one LDS-DMA instruction (one 32-B access instead of
+//                two cache-line lookups: the L1 processes about one line per clock, measured 61 cycles for a
+//                64-line instruction); the slot swizzle keeps the ds_read_b64 of 16 tiles on 64 distinct banks.
+//   U block      [n16 4][xg 4][h 2][lane 64][16 B]
+// A tile's columns 2,3 are its right neighbour's columns 0,1 — tiles are numbered linearly over (image, tile row,
+// tile column), so the neighbour is tile+1 except at the end of a tile row (or of the workgroup's 64 tiles), where
+// the two pixels come from tail j = (tile row) - (tile row of the workgroup's first tile).  That halves the patch
+// bytes against private 4x4 patches and keeps the numbering free of 2-D edge waste.  The stage is exactly 18 LDS-DMA
+// instructions (1 KiB each, lane-linear); a lane derives (row, idx) from its byte position.
+constexpr int WINO_ROW = 72 * 32;                       // 2304 B per (qy, par)
+constexpr int WINO_PATCH = 8 * WINO_ROW;                // 18432
+constexpr int WINO_NST = 3;
+constexpr int WINO_UBASE = WINO_NST * WINO_PATCH;
+constexpr int WINO_LDS = WINO_UBASE + WINO_NST * 32768;  // 153600 (the epilogue reuses 66.25 KiB of it)
+
+template <int N> __device__ __forceinline__ void wino_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int DBG, bool PERSIST>
 __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
 {
     const IgemmP &p = k.p;
@@ -116,205 +148,353 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, kg = lane >> 4;
+    const int tpi = k.tiles_x * k.tiles_y;
+    const int ns = k.nsteps;
+    const bool early = wave < 4;
 
-    // XCD-aware order: every XCD gets a contiguous run of logical workgroups; M tiles of one N tile are neighbours
-    // (they share the 32 KiB/step U stream, which is 3x the unique patch bytes).
-    int logical;
+    // ---- persistent workgroups: one per CU, each walks the (N tile, M tile) list with stride gridDim.x.  Within a
+    // pass every XCD (blockIdx & 7) gets a contiguous run of logical tiles; M tiles of one N tile are neighbours
+    // (they share the 32 KiB/step U stream, twice the patch bytes).
+    const int G = gridDim.x;
+    const int total = p.mtiles * p.ntiles;
+    int slot;
     {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int nt = logical / p.mtiles, mt = logical - nt * p.mtiles;
-    const int T0 = mt * 64, n0 = nt * 64;
 
-    // ---- DMA role.  Patch image per stage: [wm 4][q 16][half 2][tile 16][16 B]; one instruction = 2 q's of one wm.
-    // This wave fills wm = wave>>1, q = 8*(wave&1) + 2*jj + (lane>>5)  ->  qy = 2*(wave&1) + (jj>>1), qx = 2*(jj&1) + (lane>>5).
-    int d_img, d_ty, d_tx;
-    {
-        int T = T0 + (wave >> 1) * 16 + l15;
-        T = T < k.MT ? T : k.MT - 1;
-        d_img = fdiv(T, k.d_tpi);
-        const int rem = T - d_img * (k.tiles_x * k.tiles_y);
-        d_ty = fdiv(rem, k.d_tx);
-        d_tx = rem - d_ty * k.tiles_x;
-    }
-    const int d_half4 = ((lane >> 4) & 1) * 4;
-    int poff[4];
+    // ---- per-tile state
+    int T0 = 0, n0 = 0, R0 = 0;
+    constexpr int NPI = 3;
+    const int npi = wave < 2 ? 3 : 2;
+    int poff[NPI];                 // LDS-DMA source element offsets of this lane's patch instructions, -1 = zeros
+    int *poff1 = (int *)(smem + WINO_LDS + 1280) + tid;   // ... of the second source, parked in LDS: [ii][tid]
     const float *sp = nullptr;
-    int snch = 0;
-    auto setup_source = [&](int si) {
-        const GSrc &g = p.src[si];
-        sp = g.p; snch = g.nch;
+    int snch = 0, kc = 0, pissued = 0;
+    const float *ublk = nullptr;
+    int offB = 0;
+
+    // read role: lane (tile = 16*wm + l15, kg): channels 2kg, 2kg+1 of the step = bytes (kg&1)*8 of half kg>>1.
+    // Pixel (qy, qx): qx < 2 at offA + (2*qy + qx)*ROW;  qx >= 2 at offB + (2*qy + qx - 2)*ROW.
+    const int tl = wm * 16 + l15;
+    const int offA = tl * 32 + (((kg >> 1) ^ ((tl >> 3) & 1)) * 16) + (kg & 1) * 8;
+    const int b_rd = WINO_UBASE + (2 * wn) * 8192 + lane * 16;
+
+    auto setup_tile = [&](int logical) {
+        const int nt = logical / p.mtiles, mt = logical - nt * p.mtiles;
+        T0 = mt * 64; n0 = nt * 64;
+        R0 = fdiv(T0, k.d_tx);                     // global tile row (image * tiles_y + ty) of the first tile
+        // DMA role: patch instructions i = wave, wave + 8 and (waves 0,1) wave + 16
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int qy = 2 * (wave & 1) + (jj >> 1), qx = 2 * (jj & 1) + (lane >> 5);
-            const int iy = 2 * d_ty + p.oy0 - g.pad + qy, ix = 2 * d_tx + p.ox0 - g.pad + qx;
-            const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            poff[jj] = ok ? ((d_img * g.H + iy) * g.W + ix) * g.C + g.c0 + d_half4 : -1;
+        for (int ii = 0; ii < NPI; ++ii) {
+            const int pos = (wave + 8 * ii) * 1024 + lane * 16;
+            const int row = pos / WINO_ROW;
+            const int rem = pos - row * WINO_ROW;
+            const int idx = rem >> 5;
+            const int qy = row >> 1, par = row & 1, half = ((rem >> 4) & 1) ^ ((idx >> 3) & 1);
+            int T, qx;
+            bool ok = true;
+            if (idx < 64) {
+                T = T0 + idx; qx = par;
+            } else {
+                const int j = idx - 64;
+                ok = (R0 + j) * k.tiles_x <= T0 + 63;        // tile row R0 + j starts inside the workgroup's range
+                T = (R0 + j + 1) * k.tiles_x - 1;            // its last tile ...
+                T = T < T0 + 63 ? T : T0 + 63;               // ... or the workgroup's last tile
+                qx = 2 + par;
+            }
+            T = T < k.MT ? T : k.MT - 1;
+            const int img = fdiv(T, k.d_tpi);
+            const int trem = T - img * tpi;
+            const int ty = fdiv(trem, k.d_tx);
+            const int tx = trem - ty * k.tiles_x;
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                int o = -1;
+                if (si < p.nsrc && ii < npi) {
+                    const GSrc &g = p.src[si];
+                    const int iy = 2 * ty + p.oy0 - g.pad + qy, ix = 2 * tx + p.ox0 - g.pad + qx;
+                    const bool inb = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                    o = inb ? ((img * g.H + iy) * g.W + ix) * g.C + g.c0 + 4 * half : -1;
+                }
+                if (si == 0) poff[ii] = o; else if (p.nsrc > 1) poff1[ii * 512] = o;
+            }
+        }
+        sp = p.src[0].p; snch = p.src[0].nch; kc = 0; pissued = 0;
+        ublk = k.U + (size_t)nt * ns * 8192 + (4 * wave) * 256 + lane * 4;
+        {
+            const int T = T0 + tl;
+            const int R = fdiv(T, k.d_tx);
+            const bool rowend = (T - R * k.tiles_x == k.tiles_x - 1) || tl == 63;
+            int j = R - R0;
+            j = j < 7 ? j : 7;
+            const int idxB = rowend ? 64 + j : tl + 1;
+            offB = idxB * 32 + (((kg >> 1) ^ ((idxB >> 3) & 1)) * 16) + (kg & 1) * 8;
         }
     };
-    const float *ublk = k.U + (size_t)nt * k.nsteps * 8192 + (4 * wave) * 256 + lane * 4;
-    auto stage = [&](int buf, int kc, int step) {
-        unsigned char *pb = smem + buf * WINO_STAGE + ((wave >> 1) * 16 + 8 * (wave & 1)) * 512;
+
+    // Per batch a wave issues 2 (+1 for waves 0,1) patch instructions and 4 U instructions: the vmcnt waits count on it.
+    auto stage_patch = [&](int buf, int kch) {
+        unsigned char *sb = smem + buf * WINO_PATCH + wave * 1024;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const float *g = poff[jj] >= 0 ? sp + (poff[jj] + kc) : p.zeros;
-            GLDS16(g, pb + jj * 1024);
+        for (int ii = 0; ii < 2; ++ii) {
+            const float *g = poff[ii] >= 0 ? sp + (poff[ii] + kch) : p.zeros;
+            GLDS16(g, sb + ii * 8192);
         }
-        unsigned char *ub = smem + buf * WINO_STAGE + 32768 + (4 * wave) * 1024;
+        if (wave < 2) {
+            const float *g = poff[2] >= 0 ? sp + (poff[2] + kch) : p.zeros;
+            GLDS16(g, sb + 16384);
+        }
+    };
+    auto stage_u = [&](int buf, int step) {
+        unsigned char *ub = smem + WINO_UBASE + buf * 32768 + (4 * wave) * 1024;
         const float *us = ublk + (size_t)step * 8192;
 #pragma unroll
         for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
     };
+    auto issue_patch = [&]() {
+        stage_patch(pissued % WINO_NST, kc);
+        ++pissued;
+        kc += 8;
+        if (kc == snch && pissued < ns) {
+            kc = 0;
+            sp = p.src[1].p; snch = p.src[1].nch;
+#pragma unroll
+            for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff1[ii * 512];
+        }
+    };
+    // wait until only the newest batch of this wave is still in flight: kind 0 = nothing issued in it, 1 = U only, 2 = patch + U
+    auto wait_landed = [&](int kind) {
+        if (kind == 0) wino_wait_vmcnt<0>();
+        else if (kind == 1) wino_wait_vmcnt<4>();
+        else if (wave < 2) wino_wait_vmcnt<7>();
+        else wino_wait_vmcnt<6>();
+    };
 
     f32x4 acc[16][2];
-#pragma unroll
-    for (int x = 0; x < 16; ++x)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
+    f32x2 v0[16], v1[16];
+    f32x4 bf[2][2];
 
-    const int a_rd = (wm * 16) * 512 + (kg >> 1) * 256 + l15 * 16 + (kg & 1) * 8;
-    const int b_rd = 32768 + (2 * wn) * 8192 + lane * 16;
-
-    int s = 0, kc = 0;
-    setup_source(0);
-    stage(0, 0, 0);
-    __syncthreads();
-    for (int st = 0; st < k.nsteps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < k.nsteps) {
-            kc += 8;
-            if (kc == snch) { kc = 0; ++s; setup_source(s); }
-            if (DBG != 1) stage(cur ^ 1, kc, st + 1);
-        }
-        const unsigned char *sb = smem + cur * WINO_STAGE;
-        f32x2 d[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) d[q] = *(const f32x2 *)(sb + a_rd + (DBG == 3 ? 0 : q * 512));
-        f32x2 t[16], v[16];
+    // A pixels of a step -> V, column by column (B^T d on the 4 pixels of a column as they arrive, then (.) B per row
+    // in place): at most one column of raw pixels is live
+    auto load_v = [&](f32x2 (&v)[16], int buf) {
+        const unsigned char *sa = smem + buf * WINO_PATCH + offA;
+        const unsigned char *sb = smem + buf * WINO_PATCH + offB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t[j] = d[j] - d[8 + j];
-            t[4 + j] = d[4 + j] + d[8 + j];
-            t[8 + j] = d[8 + j] - d[4 + j];
-            t[12 + j] = d[4 + j] - d[12 + j];
+            const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW;
+            const f32x2 a0 = *(const f32x2 *)(src);
+            const f32x2 a1 = *(const f32x2 *)(src + 2 * WINO_ROW);
+            const f32x2 a2 = *(const f32x2 *)(src + 4 * WINO_ROW);
+            const f32x2 a3 = *(const f32x2 *)(src + 6 * WINO_ROW);
+            v[j] = pk_sub(a0, a2);
+            v[4 + j] = pk_add(a1, a2);
+            v[8 + j] = pk_sub(a2, a1);
+            v[12 + j] = pk_sub(a1, a3);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[4 * i + 0] = t[4 * i] - t[4 * i + 2];
-            v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
-            v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
-            v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+            const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
+            v[4 * i + 0] = pk_sub(t0, t2);
+            v[4 * i + 1] = pk_add(t1, t2);
+            v[4 * i + 2] = pk_sub(t2, t1);
+            v[4 * i + 3] = pk_sub(t1, t3);
         }
+    };
+    // MFMAs of xi combos [c0, c1) of a step (combo c = (xg = c>>1, h = c&1): 8 MFMAs), B fragments read one combo ahead;
+    // the scheduling barriers keep that order (the scheduler otherwise sinks the reads next to their use)
+    auto read_b = [&](int buf, int c) {
+        const unsigned char *sb = smem + buf * 32768 + b_rd;
+        bf[c & 1][0] = *(const f32x4 *)(sb + c * 1024);
+        bf[c & 1][1] = *(const f32x4 *)(sb + 8192 + c * 1024);
+    };
+    auto mfma_combos = [&](const f32x2 (&v)[16], int buf, int c0, int c1) {
 #pragma unroll
-        for (int xg = 0; xg < 4; ++xg)
+        for (int c = c0; c < c1; ++c) {
+            const int xg = c >> 1, h = c & 1;
+            if (c + 1 < 8) read_b(buf, c + 1);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 b0 = *(const f32x4 *)(sb + b_rd + (xg * 2 + h) * 1024);
-                const f32x4 b1 = *(const f32x4 *)(sb + b_rd + 8192 + (xg * 2 + h) * 1024);
+            for (int e = 0; e < 4; ++e) {
+                acc[4 * xg + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * xg + e][h], bf[c & 1][0][e], acc[4 * xg + e][0], 0, 0, 0);
+                acc[4 * xg + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * xg + e][h], bf[c & 1][1][e], acc[4 * xg + e][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- main loop of one tile, one barrier per step (at its end).  Batch of step s = patches(s+3) + U(s+2), into the
+    // buffers step s-1 freed.  During step s a wave also reads and transforms the A pixels of step s+1 (landed since
+    // the previous barrier).  End of step s: everything but this step's batch has landed -> U(s+1), patches(s+2).
+    // The two waves of a SIMD (w and w+4) run complementary schedules so that one wave's LDS-DMA issue (~200 cycles
+    // per instruction) and transform hide behind the partner's MFMAs:
+    //                   early (waves 0-3): batch, transform(s+1), 64 MFMAs
+    //                   late  (waves 4-7): 32 MFMAs, batch, 32 MFMAs, transform(s+1)
+    // Each role is its own copy of the loop (one uniform branch around the whole loop, none inside a step).
+    auto run = [&](auto role) {
+        constexpr bool EARLY = decltype(role)::value;
+        auto step = [&](int s, const f32x2 (&vc)[16], f32x2 (&vn)[16]) {
+            int kind = 0;
+            const int ub = s % WINO_NST;
+            auto batch = [&]() {
+                if (DBG != 1) {
+                    if (s + 3 < ns) { issue_patch(); kind = 2; }
+                    if (s + 2 < ns) { stage_u((s + 2) % WINO_NST, s + 2); kind = kind ? kind : 1; }
+                }
+            };
+            read_b(ub, 0);
+            if (EARLY) {
+                batch();
+                if (s + 1 < ns) load_v(vn, (s + 1) % WINO_NST);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_combos(vc, ub, 0, 8);
+            } else {
+                mfma_combos(vc, ub, 0, 4);
+                batch();
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_combos(vc, ub, 4, 8);
+                if (s + 1 < ns) load_v(vn, (s + 1) % WINO_NST);
+            }
+            wait_landed(kind);
+            __builtin_amdgcn_s_barrier();
+        };
+        int s = 0;
+        for (; s + 1 < ns; s += 2) {
+            step(s, v0, v1);
+            step(s + 1, v1, v0);
+        }
+        if (s < ns) step(s, v0, v1);
+    };
+
+    // ---- epilogue of the tile (T0c, n0c), two passes (channels 32*pass..+31: the waves with wn == pass write) through a
+    // 32 KiB staging image in U buffer 2 — the next tile's first stages are already in flight in the other buffers.
+    //   staging[256 rows = tile*4 + 2*py + px][32 n] floats | rowoff[256] | flags[256] (after the rings)
+    float *stg = (float *)(smem + WINO_UBASE + 2 * 32768);
+    unsigned *rowoff = (unsigned *)(smem + WINO_LDS);
+    unsigned char *rflag = smem + WINO_LDS + 1024;     // bit0: row outside the output domain, bit1: inside the deferred-ReLU window
+    auto epilogue = [&](int T0c, int n0c) {
+        if (tid < 256) {
+            const int tl2 = tid >> 2, py = (tid >> 1) & 1, px = tid & 1;
+            int T = T0c + tl2;
+            const bool tok = T < k.MT;
+            T = tok ? T : k.MT - 1;
+            const int img = fdiv(T, k.d_tpi);
+            const int rem = T - img * tpi;
+            const int ty = fdiv(rem, k.d_tx);
+            const int tx = rem - ty * k.tiles_x;
+            int oy = 2 * ty + py, ox = 2 * tx + px;
+            const bool ok = tok && oy < p.OH && ox < p.OW;
+            oy = oy < p.OH ? oy : p.OH - 1; ox = ox < p.OW ? ox : p.OW - 1;
+            unsigned off;
+            if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
+            else off = (unsigned)((img * p.OH + oy) * p.OW + ox) * (unsigned)p.DC;
+            rowoff[tid] = off;
+            const bool inwin = (p.rw1 > p.rw0) && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
+            rflag[tid] = (ok ? 0 : 1) | (inwin ? 2 : 0);
+        }
+        const bool relu_win = p.rw1 > p.rw0;
+        const int c4 = tid & 7;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (DBG == 2) { acc[4 * xg + e][0][0] += v[4 * xg + e][h] * b0[e]; acc[4 * xg + e][1][0] += v[4 * xg + e][h] * b1[e]; continue; }
-                    acc[4 * xg + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * xg + e][h], b0[e], acc[4 * xg + e][0], 0, 0, 0);
-                    acc[4 * xg + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * xg + e][h], b1[e], acc[4 * xg + e][1], 0, 0, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wn == pass) {
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const int n = nn * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s0[4], s1[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            s0[j] = acc[j][nn][r] + acc[4 + j][nn][r] + acc[8 + j][nn][r];
+                            s1[j] = acc[4 + j][nn][r] - acc[8 + j][nn][r] - acc[12 + j][nn][r];
+                        }
+                        const int tile = wm * 16 + 4 * kg + r;
+                        float *o = stg + (tile * 4) * 32 + n;
+                        o[0] = s0[0] + s0[1] + s0[2];
+                        o[32] = s0[1] - s0[2] - s0[3];
+                        o[64] = s1[0] + s1[1] + s1[2];
+                        o[96] = s1[1] - s1[2] - s1[3];
+                    }
                 }
             }
-        __syncthreads();
-    }
-
-    // ---- epilogue.  LDS: out[256 rows = tile*4 + 2*py + px][64 n] floats (64 KiB) | rowoff[256] | flags[256]
-    float *outp = (float *)smem;
-    unsigned *rowoff = (unsigned *)(smem + 65536);
-    unsigned char *rflag = smem + 65536 + 1024;      // bit0: row outside the output domain, bit1: inside the deferred-ReLU window
-    if (tid < 256) {
-        const int tl = tid >> 2, py = (tid >> 1) & 1, px = tid & 1;
-        int T = T0 + tl;
-        const bool tok = T < k.MT;
-        T = tok ? T : k.MT - 1;
-        const int img = fdiv(T, k.d_tpi);
-        const int rem = T - img * (k.tiles_x * k.tiles_y);
-        const int ty = fdiv(rem, k.d_tx);
-        const int tx = rem - ty * k.tiles_x;
-        int oy = 2 * ty + py, ox = 2 * tx + px;
-        const bool ok = tok && oy < p.OH && ox < p.OW;
-        oy = oy < p.OH ? oy : p.OH - 1; ox = ox < p.OW ? ox : p.OW - 1;
-        unsigned off;
-        if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
-        else off = (unsigned)((img * p.OH + oy) * p.OW + ox) * (unsigned)p.DC;
-        rowoff[tid] = off;
-        const bool inwin = (p.rw1 > p.rw0) && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
-        rflag[tid] = (ok ? 0 : 1) | (inwin ? 2 : 0);
-    }
+            __syncthreads();
+            const int ncol = n0c + 32 * pass + 4 * c4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-        const int n = wn * 32 + nn * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s0[4], s1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s0[j] = acc[j][nn][r] + acc[4 + j][nn][r] + acc[8 + j][nn][r];
-                s1[j] = acc[4 + j][nn][r] - acc[8 + j][nn][r] - acc[12 + j][nn][r];
+                for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = p.bias[p.cout ? n % p.cout : n]; }
             }
-            const int tile = wm * 16 + 4 * kg + r;
-            float *o = outp + (tile * 4) * 64 + n;
-            o[0] = s0[0] + s0[1] + s0[2];
-            o[64] = s0[1] - s0[2] - s0[3];
-            o[128] = s1[0] + s1[1] + s1[2];
-            o[192] = s1[1] - s1[2] - s1[3];
-        }
-    }
-    __syncthreads();
-
-    const int c4 = tid & 15;
-    const int ncol = n0 + 4 * c4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = p.bias[p.cout ? n % p.cout : n]; }
-    }
-    const bool relu_win = p.rw1 > p.rw0;
-#pragma unroll
-    for (int it = 0; it < 8; it += 4) {
-        f32x4 v[4];
-        size_t o[4];
-        unsigned char fl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = (it + u) * 32 + (tid >> 4);
-            v[u] = *(const f32x4 *)(outp + row * 64 + 4 * c4) + bv;
-            o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
-            fl[u] = rflag[row];
-        }
-        if (p.add) {
-            f32x4 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.add + o[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] += t[u];
-        }
-        if (p.relu) {
+            f32x4 v[4];
+            size_t o[4];
+            unsigned char fl[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool defer = relu_win && (fl[u] & 2);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] > 0.f || defer) ? v[u][c] : 0.f;
+                const int row = u * 64 + (tid >> 3);
+                v[u] = *(const f32x4 *)(stg + row * 32 + 4 * c4) + bv;
+                o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
+                fl[u] = rflag[row];
             }
-        }
-        if (p.mask) {
-            f32x4 t[4];
+            if (p.add) {
+                f32x4 t[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.mask + o[u]);
+                for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.add + o[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += t[u];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool defer = relu_win && (fl[u] & 2);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] > 0.f || defer) ? v[u][c] : 0.f;
+                }
+            }
+            if (p.mask) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.mask + o[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[u][c] = t[u][c] > 0.f ? v[u][c] : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[u][c] = t[u][c] > 0.f ? v[u][c] : 0.f;
+                if (!(fl[u] & 1)) *(f32x4 *)(p.dst + o[u]) = v[u];
+            __syncthreads();           // staging (and, after pass 1, the row tables) may be rewritten
         }
+    };
+
+    // ---- tile loop
+    int logical = slot;
+    if (logical >= total) return;
+    setup_tile(logical);
+    for (int i = 0; i < 3; ++i) issue_patch();          // ns >= 4 (every source has >= 32 channels)
+    stage_u(0, 0);
+    stage_u(1, 1);
+    while (true) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (!(fl[u] & 1)) *(f32x4 *)(p.dst + o[u]) = v[u];
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
+        wino_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        load_v(v0, 0);
+        if (early) run(std::true_type{}); else run(std::false_type{});
+        // every wave is past the last step's barrier: the rings are free.  Start the next tile's first stages, then
+        // drain this tile's accumulators while they fly.
+        const int T0c = T0, n0c = n0;
+        const int next = PERSIST ? logical + G : total;     // !PERSIST: one tile per workgroup
+        if (next < total) {
+            setup_tile(next);
+            for (int i = 0; i < 3; ++i) issue_patch();
+            stage_u(0, 0);
+            stage_u(1, 1);
+        }
+        epilogue(T0c, n0c);
+        if (next >= total) break;
+        logical = next;
     }
 }
 
@@ -324,6 +504,7 @@ bool wino_applicable(const IgemmP &p)
 {
     if (p.T != 9 || p.TX != 3 || p.stride != 1 || p.scatter == 1) return false;
     if (p.Nn % 64 != 0) return false;
+    if (cdiv(p.OW, 2) < 9) return false;      // a workgroup's 64 linear tiles may then span more than 8 tile rows (8 tails are staged)
     for (int i = 0; i < p.nsrc; ++i)
         if (p.src[i].nch % 8 != 0) return false;
     return true;
@@ -334,11 +515,16 @@ size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * Nn; }
 // p must have passed launch_igemm's argument checks (launch_igemm calls this)
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
 {
-    static bool attr_done[64] = {false};
     static const int dbg = [] { const char *e = getenv("UNET_WINO_DBG"); return e ? atoi(e) : 0; }();
-    auto kern = dbg == 1 ? wino_f32_kernel<1> : dbg == 2 ? wino_f32_kernel<2> : dbg == 3 ? wino_f32_kernel<3> : wino_f32_kernel<0>;
-    static bool attr_done1[64] = {false}, attr_done2[64] = {false}, attr_done3[64] = {false};
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, WINO_LDS, dbg == 1 ? attr_done1 : dbg == 2 ? attr_done2 : dbg == 3 ? attr_done3 : attr_done)) return rc_;
+    static const int persist = [] { const char *e = getenv("UNET_WINO_PERSIST"); return e ? atoi(e) : 0; }();
+    auto kern = dbg == 1 ? wino_f32_kernel<1, false> : persist ? wino_f32_kernel<0, true> : wino_f32_kernel<0, false>;
+    static bool attr_done[64] = {false}, attr_done1[64] = {false}, attr_done2[64] = {false};
+    constexpr int LDS = WINO_LDS + 1280 + 3 * 512 * 4;          // rings + the epilogue's row tables + parked second-source offsets
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, dbg == 1 ? attr_done1 : persist ? attr_done2 : attr_done)) return rc_;
+    static int ncu[64] = {0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!ncu[dev]) HIP_TRY(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
     WinoP q;
     q.p = p;
     q.U = U;
@@ -352,10 +538,12 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     q.d_tx = make_fastdiv((unsigned)q.tiles_x);
     q.p.mtiles = cdiv(q.MT, 64);
     q.p.ntiles = p.Nn / 64;
+    const int total = q.p.mtiles * q.p.ntiles;
+    const int grid = (!persist || total < ncu[dev]) ? total : ncu[dev];       // persist: one 512-thread workgroup per CU walks the tiles
     char tag[96];
     snprintf(tag, sizeof(tag), "wino M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
     prof_begin(0, igemm_alg_flops(p), st, tag);
-    hipLaunchKernelGGL(kern, dim3(q.p.mtiles * q.p.ntiles), dim3(512), WINO_LDS, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -60,7 +60,8 @@ def conv_mode(hip, request):
     hip.check(hip.lib().unet_set_math(0), "set_math")
 
 
-@pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32)])
+@pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32),
+                                     (3, 26, 128, 128), (1, 22, 256, 512), (2, 45, 64, 64)])
 def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1); w = rnd(K, C, 3, 3, seed=2, scale=0.05); b = rnd(K, seed=3)
@@ -72,7 +73,8 @@ def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     assert nerr(nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128)])
+@pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128),
+                                               (1, 24, 4, 64, 64, 64), (2, 30, -3, 64, 64, 128), (1, 20, 1, 128, 128, 64)])
 def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
     keep = Keep()
     """crop_and_concat (network.py:108-127) is never materialised: the conv reads two sources."""
@@ -90,7 +92,7 @@ def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
 
 
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True),
-                                                      (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False)])
+                                                      (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False), (2, 25, 128, 256, True, True)])
 def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1).requires_grad_(True)
@@ -115,7 +117,7 @@ def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     assert nerr(db, dz.sum((0, 2, 3))) < TOL
 
 
-@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 8, 0, 64, 64)])
+@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 8, 0, 64, 64), (1, 24, 4, 64, 64), (2, 30, -3, 64, 128)])
 def test_conv3x3_bwd_virtual_concat(hip, conv_mode, B, Hs, pad, C, K):
     keep = Keep()
     H = Hs + 2 * pad
