@@ -70,9 +70,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for one rank")
-    ap.add_argument("--math", type=int, default=0, choices=(0, 1, 2),
-                    help="arithmetic of the dense contractions for the MAIN measurement: 0 exact fp32 MFMA (default, the "
-                         "BASELINE config), 1 bf16x3 split, 2 bf16 compute (include/unet_hip.h unet_set_math)")
+    ap.add_argument("--math", type=int, default=3, choices=(0, 1, 2, 3),
+                    help="arithmetic of the dense contractions for the MAIN measurement: 3 fp32 MFMA with Winograd F(2x2,3x3) 3x3 "
+                         "layers (default), 0 fp32 MFMA direct convolution, 1 bf16x3 split, 2 bf16 compute (include/unet_hip.h unet_set_math)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short extra measurements of the other math modes")
     ap.add_argument("--dump-launches", default=None, help="write per-launch timings (CSV) of the timed region here")
     args = ap.parse_args()
@@ -152,9 +152,10 @@ def main():
             "metric": "572x572 tiles/sec fwd+bwd", "value": tiles / dt, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {0: "f32", 1: "bf16x3 (fp32 accumulate/storage)", 2: "bf16 (fp32 accumulate/storage)"}[args.math],
+            "vs_baseline": None, "dtype": {0: "f32", 1: "bf16x3 (fp32 accumulate/storage)", 2: "bf16 (fp32 accumulate/storage)", 3: "f32"}[args.math],
             "data": "synthetic",
             "config": {"workload": "batch=%d/GPU 572x572x1 fwd+bwd+SGD fp32, 64-base-ch U-Net (BASELINE configs[1])" % B,
+                       "arithmetic": {0: "fp32 MFMA, direct convolution", 1: "bf16x3 split", 2: "bf16", 3: "fp32 MFMA; 3x3 fwd/dgrad as Winograd F(2x2,3x3)"}[args.math],
                        "global_batch": B * world, "tile": S, "parallelism": "dp%d" % world,
                        "loss": "unweighted BCE-with-logits", "final_loss": float(loss.item())},
             "step_tflops": flops_step / (dt / args.steps) / 1e12,
@@ -162,21 +163,31 @@ def main():
         if timing:
             ms = C.c_double(); n = C.c_long(); fl = C.c_double()
             fam = {}
-            for f, name in ((0, "igemm_f32"), (1, "wgrad_f32"), (2, "wgrad_reduce")):
+            for f, name in ((0, "igemm_f32"), (1, "wgrad_f32"), (2, "wgrad_reduce"), (3, "wino_f32")):
                 _hip.check(L.unet_profile_read(f, C.byref(ms), C.byref(n), C.byref(fl)))
                 fam[name] = (ms.value, n.value, fl.value)
-            ms0, n0, fl0 = fam["igemm_f32"]
+            # the dominant kernel: Winograd 3x3 (math mode 3) or the implicit GEMM (other modes)
+            dom = "wino_f32" if fam["wino_f32"][0] > fam["igemm_f32"][0] else "igemm_f32"
+            ms0, n0, fl0 = fam[dom]
             ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # from tools/summarize_profiles.py (rocprofv3 --pmc passes)
             if os.path.exists(tpath) and B == B_PER_GPU:
-                traffic = json.load(open(tpath))["igemm_hbm_mb_per_launch"] * 1e6
-            out["roofline"] = {"bound": "mfma", "kernel": "igemm_f32_kernel (conv fwd / dgrad / up-conv implicit GEMM)",
+                traffic = json.load(open(tpath)).get("%s_hbm_mb_per_launch" % dom.split("_")[0])
+                traffic = traffic * 1e6 if traffic else None
+            kname = {"wino_f32": "wino_f32_kernel (3x3 conv fwd / dgrad, Winograd F(2x2,3x3) on the fp32 MFMA)",
+                     "igemm_f32": "igemm_f32_kernel (conv fwd / dgrad / up-conv implicit GEMM)"}[dom]
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                                "launches_per_step": n0 / args.steps, "avg_launch_ms": ms0 / max(n0, 1),
                                "gflop_per_launch": fl0 / max(n0, 1) / 1e9,
                                "share_of_step_time": ms0 / (dt * 1e3)}
+            if dom == "wino_f32":
+                # `achieved` counts the ALGORITHMIC flops of the direct 3x3 correlation; F(2x2,3x3) executes
+                # 16/36 of those multiplies on the matrix cores, so the fraction of the MFMA peak actually kept busy is:
+                out["roofline"]["executed_mfma_frac"] = ach * (16.0 / 36.0) / PEAK_F32_MFMA_TFLOPS
+                out["roofline"]["note"] = "achieved = direct-convolution flops / time; Winograd executes 16/36 of them, see executed_mfma_frac"
             if args.dump_launches:
                 _hip.check(L.unet_profile_dump(args.dump_launches.encode()))
             out["kernels"] = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
@@ -187,7 +198,7 @@ def main():
     # informational: the same step in the other arithmetic modes (not part of `value`)
     if not args.no_other_modes:
         other = {}
-        for m, name in ((1, "bf16x3_split_fp32_accumulate"), (2, "bf16_compute_fp32_accumulate")):
+        for m, name in ((0, "f32_direct"), (3, "f32_winograd_3x3"), (1, "bf16x3_split_fp32_accumulate"), (2, "bf16_compute_fp32_accumulate")):
             if m == args.math:
                 continue
             _hip.check(L.unet_set_math(m), "unet_set_math")

@@ -26,7 +26,7 @@ const float *zero_page();          // 4 KiB of device zeros on the current devic
         if (!(cond)) { unet::set_error(__VA_ARGS__); return -2; }                  \
     } while (0)
 
-// per-family event timing (prof.hip); family 0 = igemm, 1 = wgrad, 2 = wgrad reduce
+// per-family event timing (prof.hip); family 0 = igemm, 1 = wgrad, 2 = wgrad reduce, 3 = winograd
 void prof_begin(int family, double flops, hipStream_t st, const char *tag = nullptr);
 void prof_end(hipStream_t st);
 

@@ -29,9 +29,10 @@ int launch_igemmh(const IgemmP &p, hipStream_t st);
 bool igemmh_applicable(const IgemmP &p);
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st);
 
-// 0 = exact fp32 MFMA (default), 1 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores), 2 = bf16 compute,
-// 3 = fp32 with Winograd F(2x2,3x3) for the stride-1 3x3 layers (everything else as mode 0)
-static int g_math_mode = [] { const char *e = getenv("UNET_MATH"); return e ? atoi(e) : 0; }();
+// 0 = fp32 MFMA, direct (every product of the correlation: an exact fmaf chain), 1 = bf16x3 split (fp32-class accuracy on
+// the bf16 matrix cores), 2 = bf16 compute, 3 (default) = fp32 MFMA with Winograd F(2x2,3x3) for the stride-1 3x3 layers'
+// forward and dgrad (2.25x fewer multiplies, same parity tolerances; everything else as mode 0)
+static int g_math_mode = [] { const char *e = getenv("UNET_MATH"); return e ? atoi(e) : 3; }();
 int get_math_mode() { return g_math_mode; }
 void set_math_mode(int m) { g_math_mode = m; }
 

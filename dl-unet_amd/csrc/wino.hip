@@ -542,7 +542,7 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     const int grid = (!persist || total < ncu[dev]) ? total : ncu[dev];       // persist: one 512-thread workgroup per CU walks the tiles
     char tag[96];
     snprintf(tag, sizeof(tag), "wino M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
-    prof_begin(0, igemm_alg_flops(p), st, tag);
+    prof_begin(3, igemm_alg_flops(p), st, tag);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());

@@ -106,6 +106,7 @@ int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const ch
  * Optional HIP-event timing around every launch of a kernel family, recorded on the launch
  * stream (bench.py's roofline.achieved is measured with this inside its timed region).
  * family: 0 = implicit-GEMM (conv fwd / dgrad / up-conv), 1 = weight-gradient, 2 = its reduce.
+ * Families: 0 implicit GEMM (igemm*.hip), 1 weight gradient, 2 its split-K reduce, 3 Winograd 3x3 (wino.hip).
  * unet_profile_read synchronises on the recorded events and returns totals since the last reset:
  * elapsed ms, launch count and the algorithmic FLOPs (2*MAC, in-bounds taps only) of the launches. */
 int unet_profile_enable(int on);

@@ -326,8 +326,9 @@ def test_config4_shaped_training_loop_with_gpu_augmentation(tmp_path):
 def math_mode():
     import _hip
     L = _hip.lib()
+    default = L.unet_get_math()
     yield lambda m: _hip.check(L.unet_set_math(m), "unet_set_math")
-    _hip.check(L.unet_set_math(0), "unet_set_math")
+    _hip.check(L.unet_set_math(default), "unet_set_math")
 
 
 def test_bf16x3_mode_keeps_fp32_class_accuracy(math_mode, golden_dir):
@@ -357,6 +358,42 @@ def test_bf16x3_mode_keeps_fp32_class_accuracy(math_mode, golden_dir):
     margin = np.abs(yc[0, 0] - yc[0, 1]).ravel()
     safe = margin > 2e-3 * float(g["logits_norms_f64"][0])            # 10 x (2e-4 x |y|max)
     assert safe.mean() > 0.99 and (am[safe] == ref[safe]).all()
+
+
+def test_winograd_mode_is_fp32_parity_grade(math_mode, golden_dir):
+    """unet_set_math(3): the stride-1 3x3 layers (forward and dgrad) run as fp32 Winograd F(2x2,3x3) on the fp32 MFMA;
+    everything else as in mode 0.  Same tolerances as the direct fp32 path: forward 2e-5, same-branch gradients 3e-4,
+    argmax bit-exact on every pixel outside the golden's low-margin set."""
+    from oracle import parity
+    math_mode(3)
+    for S, B in ((188, 2), (220, 2), (380, 1)):
+        r = parity.check_same_branch(S, B)
+        worst = max(r["grads"].items(), key=lambda kv: kv[1])
+        print("winograd S=%d: fwd %.2e, worst grad %s %.2e" % (S, r["fwd"], worst[0], worst[1]))
+        assert r["fwd"] < FWD_TOL, r["fwd"]
+        assert worst[1] < GRAD_TOL, worst
+    import network, optim as hip_optim
+    from oracle import prng
+    g = np.load(os.path.join(golden_dir, "unet_S572_fwd.npz"))
+    net = network.Unet()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in prng.make_params(0).items()})
+    net = net.to("cuda:0")
+    with torch.no_grad():
+        y = net(torch.from_numpy(prng.make_input(1, 1, 572)).cuda())
+    assert nerr(y.cpu().numpy()[:, :, ::6, ::6], g["logits_sample_f64"]) < FWD_TOL
+    am = hip_optim.argmax2(y).cpu().numpy().ravel()
+    ref = np.unpackbits(g["argmax_packed"])[: am.size]
+    safe = np.ones(am.size, bool); safe[g["low_margin_idx"]] = False
+    assert (am[safe] == ref[safe]).all()
+
+
+def test_direct_fp32_mode(math_mode):
+    """unet_set_math(0): every layer as the direct correlation (exact fmaf chains on the fp32 MFMA)."""
+    from oracle import parity
+    math_mode(0)
+    r = parity.check_same_branch(220, 2)
+    assert r["fwd"] < FWD_TOL, r["fwd"]
+    assert max(r["grads"].values()) < GRAD_TOL
 
 
 def test_bf16_compute_mode(math_mode):

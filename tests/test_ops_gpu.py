@@ -55,9 +55,10 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.fixture(params=[0, 3], ids=["direct", "winograd"])
 def conv_mode(hip, request):
     """The 3x3 layers have two fp32 evaluations: the direct fmaf chain (math mode 0) and Winograd F(2x2,3x3) (mode 3)."""
+    default = hip.lib().unet_get_math()
     hip.check(hip.lib().unet_set_math(request.param), "set_math")
     yield request.param
-    hip.check(hip.lib().unet_set_math(0), "set_math")
+    hip.check(hip.lib().unet_set_math(default), "set_math")
 
 
 @pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32),

@@ -13,8 +13,11 @@ def short(n):
     return n.split("(")[0].replace("void ", "").replace("unet::", "")[:44]
 
 stats = list(csv.DictReader(open("profiles/%s_rocprofv3_kernel_stats.csv" % tag)))
-ig = [r for r in stats if "igemm_f32_kernel" in r["Name"]]
-ig_calls = sum(int(r["Calls"]) for r in ig); ig_ns = sum(float(r["TotalDurationNs"]) for r in ig)
+DOM = (("wino", "wino_f32_kernel"), ("igemm", "igemm_f32_kernel"))     # kernels whose traffic / launch time are reported
+calls = {}; ns = {}
+for key, sub in DOM:
+    rs = [r for r in stats if sub in r["Name"]]
+    calls[key] = sum(int(r["Calls"]) for r in rs); ns[key] = sum(float(r["TotalDurationNs"]) for r in rs)
 
 def counters(sub):
     d = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
@@ -35,7 +38,7 @@ lines = ["# %s — rocprofv3 PMC summary (bench.py --steps 2 --warmup 1, separat
          "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock); clock = GRBM_GUI_ACTIVE / 8 / duration.", "",
          "| kernel | launches | ms total | clock GHz | MFMA busy | WAIT_ANY/WAVE | fetch MB/launch (x2) | write MB/launch | LDS bank-conflict cycles / LDS active |",
          "|---|---|---|---|---|---|---|---|---|"]
-tot_f = tot_w = tot_n = 0
+tot_f = collections.Counter(); tot_w = collections.Counter(); tot_n = collections.Counter()
 for k in sorted(dur, key=lambda k: -dur[k])[:14]:
     c = sq[k]; clk = c["GRBM_GUI_ACTIVE"] / 8 / dur[k] if dur[k] else 0
     busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * dur[k] * clk) if clk else 0
@@ -43,13 +46,23 @@ for k in sorted(dur, key=lambda k: -dur[k])[:14]:
     lb = ld[k]["SQ_LDS_BANK_CONFLICT"] / max(ld[k]["SQ_ACTIVE_INST_LDS"], 1)
     lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.3f |" % (k, nsq[k], dur[k] / 1e6, clk, busy,
                  c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), f, w, lb))
-    if "igemm_f32_kernel" in k:
-        tot_f += 2 * fe[k]["FETCH_SIZE"] / 1024; tot_w += wr[k]["WRITE_SIZE"] / 1024; tot_n += nfe[k]
-traffic = (tot_f + tot_w) / max(tot_n, 1)
-lines += ["", "igemm_f32_kernel (all instantiations): HBM traffic %.1f MB per launch (fetch %.1f + write %.1f), %d launches." %
-          (traffic, tot_f / tot_n, tot_w / tot_n, tot_n),
-          "rocprofv3 --stats (bench.py --steps 5 --warmup 2): igemm avg launch %.4f ms over %d calls; bench.py HIP events: %.4f ms." %
-          (ig_ns / ig_calls / 1e6, ig_calls, bench["roofline"]["avg_launch_ms"])]
+    for key, sub in DOM:
+        if sub in k:
+            tot_f[key] += 2 * fe[k]["FETCH_SIZE"] / 1024; tot_w[key] += wr[k]["WRITE_SIZE"] / 1024; tot_n[key] += nfe[k]
+out = {"source": "profiles/%s_pmc_summary.md" % tag}
+lines.append("")
+bench_dom = "wino" if "wino" in bench["roofline"]["kernel"] else "igemm"
+for key, sub in DOM:
+    if not tot_n[key]:
+        continue
+    traffic = (tot_f[key] + tot_w[key]) / tot_n[key]
+    out["%s_hbm_mb_per_launch" % key] = traffic
+    lines.append("%s (all instantiations): HBM traffic %.1f MB per launch (fetch %.1f + write %.1f), %d launches." %
+                 (sub, traffic, tot_f[key] / tot_n[key], tot_w[key] / tot_n[key], tot_n[key]))
+    if calls[key]:
+        lines.append("rocprofv3 --stats (bench.py --steps 5 --warmup 2): %s avg launch %.4f ms over %d calls%s." %
+                     (sub, ns[key] / calls[key] / 1e6, calls[key],
+                      "; bench.py HIP events: %.4f ms" % bench["roofline"]["avg_launch_ms"] if key == bench_dom else ""))
 open("profiles/%s_pmc_summary.md" % tag, "w").write("\n".join(lines) + "\n")
-json.dump({"igemm_hbm_mb_per_launch": traffic, "source": "profiles/%s_pmc_summary.md" % tag}, open("profiles/pmc_traffic.json", "w"))
-print("\n".join(lines[-3:]))
+json.dump(out, open("profiles/pmc_traffic.json", "w"))
+print("\n".join(lines[-5:]))
