@@ -46,7 +46,10 @@ typedef struct unet_config {
 const char *unet_last_error(void);
 int unet_abi_version(void);
 
-/* Arithmetic of the dense contractions (process-wide): 0 = exact fp32 MFMA (default; fmaf-chain numerics),
+/* Arithmetic of the dense contractions (process-wide):
+ * 3 = fp32 on the fp32 MFMA, the stride-1 3x3 layers' forward and dgrad as Winograd F(2x2,3x3) (default: 16 of the 36
+ *     multiplies of the direct correlation, all arithmetic fp32, same parity tolerances as mode 0),
+ * 0 = fp32 on the fp32 MFMA, direct correlation everywhere (fmaf-chain numerics),
  * 1 = bf16x3: fp32 operands split into two bf16 terms, three bf16 MFMAs per product, fp32 accumulation
  *     (~16-bit products; logits stay within ~1e-5 of fp32), 2 = bf16 operands, fp32 accumulation and storage
  *     (BASELINE config #3).  Tensors in HBM stay fp32 in every mode.  Also settable with UNET_MATH.           */
