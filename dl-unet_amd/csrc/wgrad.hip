@@ -16,10 +16,15 @@
 #include "common.hpp"
 #include <array>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
 namespace unet {
+
+bool wgradw_applicable(const WgradP &p);
+size_t wgradw_slab_need(const WgradP &p);
+int launch_wgradw(const WgradP &p, hipStream_t st);
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -345,10 +350,13 @@ size_t wgrad_slab_need(const WgradP &p)
 {
     WgradK k{};
     decompose(p, k);
-    return (size_t)k.ngroups * k.pstride * sizeof(float);
+    const size_t a = (size_t)k.ngroups * k.pstride * sizeof(float), b = wgradw_slab_need(p);
+    return a > b ? a : b;
 }
 
-static double wgrad_alg_flops(const WgradP &p)
+double wgrad_alg_flops_pub(const WgradP &p);
+static double wgrad_alg_flops(const WgradP &p) { return wgrad_alg_flops_pub(p); }
+double wgrad_alg_flops_pub(const WgradP &p)
 {
     long cy = 0, cx = 0;
     for (int y = 0; y < p.YH; ++y)
@@ -383,6 +391,8 @@ int launch_wgrad(WgradP p, hipStream_t st)
     ARG_CHECK((size_t)p.NB * p.XH * p.XW * p.XC < 0x7FFFFFFFull * 2 && (size_t)p.NB * p.YH * p.YW * p.YC < 0x7FFFFFFFull * 2, "wgrad: tensor too large");
     p.zeros = zero_page();
     if (!p.zeros) return -2;
+    static const int ww = [] { const char *e = getenv("UNET_WGRADW"); return e ? atoi(e) : 1; }();
+    if (get_math_mode() == 3 && ww && wgradw_applicable(p)) return launch_wgradw(p, st);     // Winograd F(3x3 <- 2x2) (wgradw.hip)
     WgradK k{};
     k.p = p;
     decompose(p, k);

@@ -1,0 +1,420 @@
+// wgradw.hip — weight gradient of the stride-1 3x3 convolutions as fp32 Winograd F(3x3 <- 4x4 input, 2x2 dz) on the
+// gfx950 matrix cores (autograd backward of network.py:131-188's convs; the direct version is wgrad.hip).
+//
+//   forward  Y = A^T [ (G g G^T) (.) (B^T d B) ] A     per 2x2 output tile
+//   =>       dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G
+//   dU[xi][ci][cj] = sum_tiles V[xi][tile][ci] * Z[xi][tile][cj]      16 GEMMs whose K dimension is the tile index:
+//                                                                     16 instead of 36 multiplies per (tile, ci, cj)
+// All arithmetic is fp32 (v_mfma_f32_16x16x4_f32 + fp32 adds).
+//
+// One 512-thread workgroup (8 waves, 2 per SIMD) owns a 64(ci) x 64(cj) channel tile for all 16 xi — 128 accumulator
+// VGPRs per wave (wave = 16 ci x 32 cj), the same budget as wino.hip — and a contiguous range of tile slots (split K).
+// Tile slots are numbered linearly over (image, tile row, tile column 0..TX) where column TX is a GHOST tile: it only
+// carries the two pixel columns right of the row's last tile and has dz = 0.  With it every tile's pixel columns 2,3
+// are simply the next slot's columns 0,1, so a K step of 16 slots stages [8 (qy,par) rows][4 channel blocks][16 slots]
+// [64 B] of input = 32 KiB (+ 2 KiB for the slot after the step's last one) and [4 px][4 blocks][16 slots][64 B] of dz
+// = 16 KiB by LDS-DMA, 6 (7) instructions per wave, into a 3-deep ring; per step a wave runs 128 MFMAs.  Both
+// transforms happen in registers, two tiles per lane in packed fp32 (v_pk_add_f32):
+//   lane (channel l15, k = kg) reads its tiles' pixels channel-wise (ds_read_b32, 64 lanes = 256 contiguous bytes),
+//   V = B^T d B (32 packed adds), Z = A dY A^T up to signs (12 packed adds; the signs are applied in the reduce),
+//   and V[xi] / Z[xi] are exactly the A / B operands of the 16x16x4 MFMA (M = ci, N = cj, K = 4 tiles).
+// Partial dU slabs are reduced in a fixed order by wgradw_reduce_kernel, which also applies G^T . G and writes the
+// 3x3 gradient in the caller's layout; the fused bias gradient is the sum of the dz values a wave reads anyway.
+#include "common.hpp"
+#include "igemm_epilogue.hpp"
+#include <cstdio>
+#include <cstdlib>
+
+namespace unet {
+
+#define GLDS16(gptr, lptr)                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WgradWK {
+    WgradP p;
+    int TXn, TXg, TYn;        // real tiles per row, slots per row (TXn + 1), tile rows
+    int wy0, wx0;             // Y-domain origin of tile (0,0)
+    int NTg;                  // NB * TYn * TXg slots
+    int nsteps, steps_per;    // K steps (16 slots) in total / per workgroup
+    int ntile_i, ntile_j, nsplit;
+    FastDiv d_spi, d_txg;     // slots per image, slots per row
+    size_t pstride;           // floats per slab
+};
+
+constexpr int WW_PATCH = 32768, WW_EXTRA = 2048, WW_DY = 16384;
+constexpr int WW_STAGE = WW_PATCH + WW_EXTRA + WW_DY;       // 51200
+constexpr int WW_NST = 3;
+constexpr int WW_LDS = WW_NST * WW_STAGE;                   // 153600
+constexpr int WW_SLAB = 16 * 64 * 64 + 64;                  // dU partial + bias partial (floats)
+
+template <int N> __device__ __forceinline__ void ww_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ f32x2 wpk_add(f32x2 a, f32x2 b)
+{
+#ifdef WW_ASM_PK
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a + b;
+#endif
+}
+__device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b)
+{
+#ifdef WW_ASM_PK
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a - b;
+#endif
+}
+
+__global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
+{
+    const WgradP &p = k.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l15 = lane & 15, kg = lane >> 4;
+
+    // XCD-aware order: consecutive logical workgroups = the channel tiles of one K range (they read the same pixels)
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int ntile = k.ntile_i * k.ntile_j;
+    const int part = logical / ntile, tile = logical - part * ntile;
+    const int it = tile / k.ntile_j, jt = tile - it * k.ntile_j;
+    const int s0 = part * k.steps_per;
+    int s1 = s0 + k.steps_per;
+    s1 = s1 < k.nsteps ? s1 : k.nsteps;
+    const int ns = s1 > s0 ? s1 - s0 : 0;
+
+    // ---- DMA role.  lane -> (slot = lane>>2, 16-B chunk = lane&3); this wave stages channel block cb = wave&3 of
+    // patch rows (qy = 0..3, par = (wave>>2)&1) and of dz pixels (py = 0..1, px = (wave>>2)&1); waves 0,1 also stage the
+    // "extra" slot (the one after the step's last): lane -> (row = (lane>>4) + 4*wave, cb = (lane>>2)&3, chunk).
+    const int d_slot = lane >> 2, d_chunk = lane & 3;
+    const int d_cb = wave & 3, d_par = (wave >> 2) & 1;
+    const int xch = p.xc0 + it * 64 + d_cb * 16 + d_chunk * 4;
+    const int ych = p.yc0 + jt * 64 + d_cb * 16 + d_chunk * 4;
+    const int e_row = (lane >> 4) + 4 * wave, e_cb = (lane >> 2) & 3;      // waves 0,1 only
+    const int e_xch = p.xc0 + it * 64 + e_cb * 16 + d_chunk * 4;
+    const int spi = k.TYn * k.TXg;
+
+    auto stage = [&](int buf, int step) {
+        unsigned char *sb = smem + buf * WW_STAGE;
+        const int T = step * 16 + d_slot;
+        const bool tok = T < k.NTg;
+        const int Tc = tok ? T : k.NTg - 1;
+        const int img = fdiv(Tc, k.d_spi);
+        const int rem = Tc - img * spi;
+        const int ty = fdiv(rem, k.d_txg);
+        const int txg = rem - ty * k.TXg;
+        // input patch: pixel (qy, par) of the slot
+        {
+            const int iy0 = (k.wy0 + 2 * ty + p.oy0) - p.xpad, ix = (k.wx0 + 2 * txg + p.ox0) - p.xpad + d_par;
+            const bool xok = tok && (unsigned)ix < (unsigned)p.XW;
+            const int base = ((img * p.XH + iy0) * p.XW + ix) * p.XC + xch;
+#pragma unroll
+            for (int qy = 0; qy < 4; ++qy) {
+                const bool ok = xok && (unsigned)(iy0 + qy) < (unsigned)p.XH;
+                const float *g = ok ? p.X + (base + qy * p.XW * p.XC) : p.zeros;
+                GLDS16(g, sb + ((qy * 2 + d_par) * 4 + d_cb) * 1024);
+            }
+        }
+        // dz: pixel (py, px = d_par) of the slot; ghost slots and pixels outside the tensor read zeros
+        {
+            const int yy0 = k.wy0 + 2 * ty, xx = k.wx0 + 2 * txg + d_par;
+            const bool xok = tok && txg < k.TXn && xx < p.YW;
+            const int base = ((img * p.YH + yy0) * p.YW + xx) * p.YC + ych;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const bool ok = xok && yy0 + py < p.YH;
+                const float *g = ok ? p.Y + (base + py * p.YW * p.YC) : p.zeros;
+                GLDS16(g, sb + WW_PATCH + WW_EXTRA + ((py * 2 + d_par) * 4 + d_cb) * 1024);
+            }
+        }
+        if (wave < 2) {
+            // extra slot = slot 16 of the step: patch rows only.  (It is slot 0 of the next step; if that starts a new
+            // tile row the current row's last slot was a ghost and nobody reads the extra slot.)
+            const int Te = step * 16 + 16;
+            const bool eok = Te < k.NTg;
+            const int Tec = eok ? Te : k.NTg - 1;
+            const int eimg = fdiv(Tec, k.d_spi);
+            const int erem = Tec - eimg * spi;
+            const int ety = fdiv(erem, k.d_txg);
+            const int etxg = erem - ety * k.TXg;
+            const int qy = e_row >> 1, par = e_row & 1;
+            const int iy = (k.wy0 + 2 * ety + p.oy0) - p.xpad + qy, ix = (k.wx0 + 2 * etxg + p.ox0) - p.xpad + par;
+            const bool ok = eok && (unsigned)iy < (unsigned)p.XH && (unsigned)ix < (unsigned)p.XW;
+            const float *g = ok ? p.X + (((eimg * p.XH + iy) * p.XW + ix) * p.XC + e_xch) : p.zeros;
+            GLDS16(g, sb + WW_PATCH + wave * 1024);
+        }
+    };
+    // wait until only the newest batch (one stage) of this wave is still in flight, or nothing
+    auto wait_landed = [&](bool one_in_flight) {
+        if (!one_in_flight) ww_wait_vmcnt<0>();
+        else if (wave < 2) ww_wait_vmcnt<7>();
+        else ww_wait_vmcnt<6>();
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
+    f32x2 dbacc[2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+    // ---- read role: lane (channel l15, k = kg).  Tile pairs (kg, kg+4) and (kg+8, kg+12): .x / .y of the packed values.
+    // patch[(row)*4096 + cb*1024 + slot*64 + ch*4], row = 2*qy + par; columns 2,3 of slot t are columns 0,1 of slot t+1;
+    // slot 16 lives in the extra region [row][cb][64 B].
+    const int a_base = wi * 1024 + l15 * 4;
+    const int e_base = WW_PATCH + wi * 64 + l15 * 4;
+    const bool last = kg == 3;                      // this lane's tile kg+12 = 15: its neighbour is the extra slot
+    const int y_base = WW_PATCH + WW_EXTRA + l15 * 4;
+
+    auto compute = [&](int buf) {
+        const unsigned char *sb = smem + buf * WW_STAGE;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int tA = kg + 8 * pr;             // .x tile; .y tile = tA + 4
+            // ---- V = B^T d B for the two tiles, column by column
+            f32x2 v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 a[4];
+#pragma unroll
+                for (int qy = 0; qy < 4; ++qy) {
+                    const int row = 2 * qy + (j & 1);
+                    if (j < 2) {
+                        const unsigned char *src = sb + a_base + row * 4096 + tA * 64;
+                        a[qy][0] = *(const float *)(src);
+                        a[qy][1] = *(const float *)(src + 256);
+                    } else {
+                        const unsigned char *src = sb + a_base + row * 4096 + (tA + 1) * 64;
+                        a[qy][0] = *(const float *)(src);
+                        if (pr == 0) {
+                            a[qy][1] = *(const float *)(src + 256);
+                        } else {
+                            const unsigned char *s2 = last ? sb + e_base + row * 256 : src + 256;
+                            a[qy][1] = *(const float *)(s2);
+                        }
+                    }
+                }
+                v[j] = wpk_sub(a[0], a[2]);
+                v[4 + j] = wpk_add(a[1], a[2]);
+                v[8 + j] = wpk_sub(a[2], a[1]);
+                v[12 + j] = wpk_sub(a[1], a[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
+                v[4 * i + 0] = wpk_sub(t0, t2);
+                v[4 * i + 1] = wpk_add(t1, t2);
+                v[4 * i + 2] = wpk_sub(t2, t1);
+                v[4 * i + 3] = wpk_sub(t1, t3);
+            }
+            // ---- per cj block: Z = A dY A^T up to signs (applied in the reduce), then 32 MFMAs
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned char *ys = sb + y_base + (2 * wj + c) * 1024 + tA * 64;
+                f32x2 d[4];
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    d[px][0] = *(const float *)(ys + px * 4096);
+                    d[px][1] = *(const float *)(ys + px * 4096 + 256);
+                }
+                // dY = [[a, b], [c, d]] = d[0], d[1], d[2], d[3]
+                f32x2 z[16];
+                const f32x2 s1 = wpk_add(d[0], d[2]), s2 = wpk_add(d[1], d[3]);
+                const f32x2 s3 = wpk_sub(d[0], d[2]), s4 = wpk_sub(d[1], d[3]);
+                z[0] = d[0];  z[1] = wpk_add(d[0], d[1]); z[2] = wpk_sub(d[0], d[1]); z[3] = d[1];        // sign(3)  = -
+                z[4] = s1;    z[5] = wpk_add(s1, s2);     z[6] = wpk_sub(s1, s2);     z[7] = s2;          // sign(7)  = -
+                z[8] = s3;    z[9] = wpk_add(s3, s4);     z[10] = wpk_sub(s3, s4);    z[11] = s4;         // sign(11) = -
+                z[12] = d[2]; z[13] = wpk_add(d[2], d[3]); z[14] = wpk_sub(d[2], d[3]); z[15] = d[3];     // sign(12,13,14) = -
+                dbacc[c] = wpk_add(dbacc[c], wpk_add(z[1], z[13]));
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int x = 0; x < 16; ++x)
+                        acc[x][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x][h], z[x][h], acc[x][c], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- pipeline: stage s+2 is issued at the start of step s (into the buffer step s-1 freed); at the end of step s
+    // everything but that batch has landed -> stage s+1.
+    if (ns > 0) {
+        stage(0, s0);
+        if (ns > 1) stage(1, s0 + 1);
+        wait_landed(ns > 1);
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < ns; ++s) {
+            const bool more = s + 2 < ns;
+            if (more) stage((s + 2) % WW_NST, s0 + s + 2);
+            compute(s % WW_NST);
+            wait_landed(more);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- slab: [xi 16][ci 64][cj 64] | db[64].  D lane layout: ci = 4*kg + r, cj = l15.
+    float *slab = p.slab + (size_t)(tile * k.nsplit + part) * k.pstride;
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(x * 64 + wi * 16 + 4 * kg + r) * 64 + (2 * wj + c) * 16 + l15] = acc[x][c][r];
+    if (wi == 0) {
+        // bias partial: sum over this lane's tiles (.x + .y) and over the 4 k groups (lanes l15 + 16*kg)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float v = dbacc[c][0] + dbacc[c][1];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kg == 0) slab[16 * 64 * 64 + (2 * wj + c) * 16 + l15] = v;
+        }
+    }
+}
+
+// out[(i0+i)*si + (j0+j)*sj + t*st] = (G^T (sigma (.) sum_parts dU) G)[t],  db[j] = sum_parts
+__global__ __launch_bounds__(256) void wgradw_reduce_kernel(const float *__restrict__ slab, int nsplit, size_t pstride, int ntile_j,
+                                                            float *__restrict__ out, long si, long sj, long st,
+                                                            float *__restrict__ db, int db_c0)
+{
+    // block = one (tile, ci); 64 threads along cj x 4 part groups
+    const int tile = blockIdx.x >> 6, i = blockIdx.x & 63;
+    const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const float *src = slab + (size_t)tile * nsplit * pstride + (size_t)i * 64 + j;
+    float m[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) m[x] = 0.f;
+    for (int P = grp; P < nsplit; P += 4) {
+        const float *s = src + (size_t)P * pstride;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) m[x] += s[x * 4096];
+    }
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) red[grp][x][j] = m[x];
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) m[x] = (red[0][x][j] + red[1][x][j]) + (red[2][x][j] + red[3][x][j]);
+        m[3] = -m[3]; m[7] = -m[7]; m[11] = -m[11]; m[12] = -m[12]; m[13] = -m[13]; m[14] = -m[14];
+        // r = G^T m (3x4), dg = r G (3x3);  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+        float r[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            r[0][c] = m[c] + 0.5f * (m[4 + c] + m[8 + c]);
+            r[1][c] = 0.5f * (m[4 + c] - m[8 + c]);
+            r[2][c] = 0.5f * (m[4 + c] + m[8 + c]) + m[12 + c];
+        }
+        const int it = tile / ntile_j, jt = tile - it * ntile_j;
+        float *o = out + (size_t)(it * 64 + i) * si + (size_t)(jt * 64 + j) * sj;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            o[(a * 3 + 0) * st] = r[a][0] + 0.5f * (r[a][1] + r[a][2]);
+            o[(a * 3 + 1) * st] = 0.5f * (r[a][1] - r[a][2]);
+            o[(a * 3 + 2) * st] = 0.5f * (r[a][1] + r[a][2]) + r[a][3];
+        }
+    }
+    if (db && i == 0 && (tile / ntile_j) == 0) {
+        // bias gradient of channel tile jt: slabs of the tiles (it = 0, jt)
+        __syncthreads();
+        const int jt = tile % ntile_j;
+        float v = 0.f;
+        for (int P = grp; P < nsplit; P += 4) v += slab[((size_t)tile * nsplit + P) * pstride + 16 * 64 * 64 + j];
+        red[grp][0][j] = v;
+        __syncthreads();
+        if (grp == 0) db[db_c0 + jt * 64 + j] = (red[0][0][j] + red[1][0][j]) + (red[2][0][j] + red[3][0][j]);
+    }
+}
+
+bool wgradw_applicable(const WgradP &p)
+{
+    if (p.TY != 3 || p.TX != 3 || p.stride != 1) return false;
+    if (p.Ci % 64 != 0 || p.Cj % 64 != 0 || p.db_on_x) return false;
+    return true;
+}
+
+static int ww_cus()
+{
+    static int ncu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!ncu[dev] && hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu[dev] = 256;
+    return ncu[dev];
+}
+
+static void ww_decompose(const WgradP &p, WgradWK &k, int cus)
+{
+    k.p = p;
+    k.wy0 = p.ywin0; k.wx0 = p.xwin0;
+    k.TYn = cdiv(p.ywin1 - p.ywin0, 2);
+    k.TXn = cdiv(p.xwin1 - p.xwin0, 2);
+    k.TXg = k.TXn + 1;
+    k.NTg = p.NB * k.TYn * k.TXg;
+    k.nsteps = cdiv(k.NTg, 16);
+    k.ntile_i = p.Ci / 64; k.ntile_j = p.Cj / 64;
+    const int ntile = k.ntile_i * k.ntile_j;
+    int nsplit = cus / ntile;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > k.nsteps) nsplit = k.nsteps;
+    k.nsplit = nsplit;
+    k.steps_per = cdiv(k.nsteps, nsplit);
+    k.d_spi = make_fastdiv((unsigned)(k.TYn * k.TXg));
+    k.d_txg = make_fastdiv((unsigned)k.TXg);
+    k.pstride = WW_SLAB;
+}
+
+size_t wgradw_slab_need(const WgradP &p)
+{
+    if (!wgradw_applicable(p)) return 0;
+    WgradWK k;
+    ww_decompose(p, k, 256);          // sized for the largest device (the split never exceeds the CU count)
+    return (size_t)k.ntile_i * k.ntile_j * k.nsplit * k.pstride * sizeof(float);
+}
+
+double wgrad_alg_flops_pub(const WgradP &p);
+
+int launch_wgradw(const WgradP &p, hipStream_t st)
+{
+    static bool attr_done[64] = {false};
+    if (int rc_ = ensure_dynamic_lds((const void *)wgradw_f32_kernel, WW_LDS, attr_done)) return rc_;
+    WgradWK k;
+    int cus = ww_cus();
+    if (cus > 256) cus = 256;
+    ww_decompose(p, k, cus);
+    const int ntile = k.ntile_i * k.ntile_j;
+    const size_t need = (size_t)ntile * k.nsplit * k.pstride * sizeof(float);
+    ARG_CHECK(need <= p.slab_bytes, "wgradw: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
+    ARG_CHECK((size_t)p.NB * p.XH * p.XW * p.XC < 0x7FFFFFFFull && (size_t)p.NB * p.YH * p.YW * p.YC < 0x7FFFFFFFull,
+              "wgradw: tensor exceeds 31-bit element offsets");
+    if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgradw: fused bias gradient needs the full Y window");
+    char tag[96];
+    snprintf(tag, sizeof(tag), "wgradw Ci=%d Cj=%d Y=%dx%d tiles=%dx%d steps=%d split=%d", p.Ci, p.Cj, p.YH, p.YW, k.TYn, k.TXn, k.nsteps, k.nsplit);
+    prof_begin(1, wgrad_alg_flops_pub(p), st, tag);
+    hipLaunchKernelGGL(wgradw_f32_kernel, dim3(ntile * k.nsplit), dim3(512), WW_LDS, st, k);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    prof_begin(2, 0.0, st);
+    hipLaunchKernelGGL(wgradw_reduce_kernel, dim3(ntile * 64), dim3(256), 0, st, p.slab, k.nsplit, k.pstride, k.ntile_j,
+                       p.out, p.si, p.sj, p.st, p.db, p.yc0);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace unet

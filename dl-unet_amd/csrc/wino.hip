@@ -127,15 +127,11 @@ template <int N> __device__ __forceinline__ void wino_wait_vmcnt() { asm volatil
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
 {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return a + b;      // selected as v_pk_add_f32 (inline asm here hid the VALU->MFMA hazards from the compiler)
 }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
 {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return a - b;
 }
 
 template <int DBG, bool PERSIST>
