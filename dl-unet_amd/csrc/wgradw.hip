@@ -73,6 +73,18 @@ __device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b)
 #endif
 }
 
+// N x { 1 MFMA, then VALU_ VALU and DS_ LDS-read instructions }: the order imposed on the scheduling region that ends here
+template <int N, int VALU_, int DS_> __device__ __forceinline__ void ww_interleave()
+{
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (DS_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, DS_, 0);
+        if constexpr (VALU_ > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_, 0);
+        ww_interleave<N - 1, VALU_, DS_>();
+    }
+}
+
+template <int DBG, bool SCHED>
 __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
 {
     const WgradP &p = k.p;
@@ -100,16 +112,18 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     // ---- DMA role.  lane -> (slot = lane>>2, 16-B chunk = lane&3); this wave stages channel block cb = wave&3 of
     // patch rows (qy = 0..3, par = (wave>>2)&1) and of dz pixels (py = 0..1, px = (wave>>2)&1); waves 0,1 also stage the
     // "extra" slot (the one after the step's last): lane -> (row = (lane>>4) + 4*wave, cb = (lane>>2)&3, chunk).
-    const int d_slot = lane >> 2, d_chunk = lane & 3;
     const int d_cb = wave & 3, d_par = (wave >> 2) & 1;
-    const int xch = p.xc0 + it * 64 + d_cb * 16 + d_chunk * 4;
-    const int ych = p.yc0 + jt * 64 + d_cb * 16 + d_chunk * 4;
-    const int e_row = (lane >> 4) + 4 * wave, e_cb = (lane >> 2) & 3;      // waves 0,1 only
-    const int e_xch = p.xc0 + it * 64 + e_cb * 16 + d_chunk * 4;
     const int spi = k.TYn * k.TXg;
 
     auto stage = [&](int buf, int step) {
         unsigned char *sb = smem + buf * WW_STAGE;
+        // the lane-derived roles are recomputed per call (a handful of VALU) instead of living in VGPRs across the loop:
+        // the opaque copy keeps the compiler from hoisting them
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int d_slot = ln >> 2, d_chunk = ln & 3;
+        const int xch = p.xc0 + it * 64 + d_cb * 16 + d_chunk * 4;
+        const int ych = p.yc0 + jt * 64 + d_cb * 16 + d_chunk * 4;
         const int T = step * 16 + d_slot;
         const bool tok = T < k.NTg;
         const int Tc = tok ? T : k.NTg - 1;
@@ -151,6 +165,8 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
             const int erem = Tec - eimg * spi;
             const int ety = fdiv(erem, k.d_txg);
             const int etxg = erem - ety * k.TXg;
+            const int e_row = (ln >> 4) + 4 * wave, e_cb = (ln >> 2) & 3;
+            const int e_xch = p.xc0 + it * 64 + e_cb * 16 + d_chunk * 4;
             const int qy = e_row >> 1, par = e_row & 1;
             const int iy = (k.wy0 + 2 * ety + p.oy0) - p.xpad + qy, ix = (k.wx0 + 2 * etxg + p.ox0) - p.xpad + par;
             const bool ok = eok && (unsigned)iy < (unsigned)p.XH && (unsigned)ix < (unsigned)p.XW;
@@ -182,75 +198,69 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     const bool last = kg == 3;                      // this lane's tile kg+12 = 15: its neighbour is the extra slot
     const int y_base = WW_PATCH + WW_EXTRA + l15 * 4;
 
-    auto compute = [&](int buf) {
+    // V = B^T d B for the tile pair pr (.x tile kg + 8 pr, .y tile +4), column by column
+    auto load_v = [&](int buf, int pr, f32x2 (&v)[16]) {
         const unsigned char *sb = smem + buf * WW_STAGE;
+        const int tA = kg + 8 * pr;
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const int tA = kg + 8 * pr;             // .x tile; .y tile = tA + 4
-            // ---- V = B^T d B for the two tiles, column by column
-            f32x2 v[16];
+        for (int j = 0; j < 4; ++j) {
+            f32x2 a[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x2 a[4];
-#pragma unroll
-                for (int qy = 0; qy < 4; ++qy) {
-                    const int row = 2 * qy + (j & 1);
-                    if (j < 2) {
-                        const unsigned char *src = sb + a_base + row * 4096 + tA * 64;
-                        a[qy][0] = *(const float *)(src);
+            for (int qy = 0; qy < 4; ++qy) {
+                const int row = 2 * qy + (j & 1);
+                if (j < 2) {
+                    const unsigned char *src = sb + a_base + row * 4096 + tA * 64;
+                    a[qy][0] = *(const float *)(src);
+                    a[qy][1] = *(const float *)(src + 256);
+                } else {
+                    const unsigned char *src = sb + a_base + row * 4096 + (tA + 1) * 64;
+                    a[qy][0] = *(const float *)(src);
+                    if (pr == 0) {
                         a[qy][1] = *(const float *)(src + 256);
                     } else {
-                        const unsigned char *src = sb + a_base + row * 4096 + (tA + 1) * 64;
-                        a[qy][0] = *(const float *)(src);
-                        if (pr == 0) {
-                            a[qy][1] = *(const float *)(src + 256);
-                        } else {
-                            const unsigned char *s2 = last ? sb + e_base + row * 256 : src + 256;
-                            a[qy][1] = *(const float *)(s2);
-                        }
+                        const unsigned char *s2 = last ? sb + e_base + row * 256 : src + 256;
+                        a[qy][1] = *(const float *)(s2);
                     }
                 }
-                v[j] = wpk_sub(a[0], a[2]);
-                v[4 + j] = wpk_add(a[1], a[2]);
-                v[8 + j] = wpk_sub(a[2], a[1]);
-                v[12 + j] = wpk_sub(a[1], a[3]);
             }
+            v[j] = wpk_sub(a[0], a[2]);
+            v[4 + j] = wpk_add(a[1], a[2]);
+            v[8 + j] = wpk_sub(a[2], a[1]);
+            v[12 + j] = wpk_sub(a[1], a[3]);
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
-                v[4 * i + 0] = wpk_sub(t0, t2);
-                v[4 * i + 1] = wpk_add(t1, t2);
-                v[4 * i + 2] = wpk_sub(t2, t1);
-                v[4 * i + 3] = wpk_sub(t1, t3);
-            }
-            // ---- per cj block: Z = A dY A^T up to signs (applied in the reduce), then 32 MFMAs
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const unsigned char *ys = sb + y_base + (2 * wj + c) * 1024 + tA * 64;
-                f32x2 d[4];
-#pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    d[px][0] = *(const float *)(ys + px * 4096);
-                    d[px][1] = *(const float *)(ys + px * 4096 + 256);
-                }
-                // dY = [[a, b], [c, d]] = d[0], d[1], d[2], d[3]
-                f32x2 z[16];
-                const f32x2 s1 = wpk_add(d[0], d[2]), s2 = wpk_add(d[1], d[3]);
-                const f32x2 s3 = wpk_sub(d[0], d[2]), s4 = wpk_sub(d[1], d[3]);
-                z[0] = d[0];  z[1] = wpk_add(d[0], d[1]); z[2] = wpk_sub(d[0], d[1]); z[3] = d[1];        // sign(3)  = -
-                z[4] = s1;    z[5] = wpk_add(s1, s2);     z[6] = wpk_sub(s1, s2);     z[7] = s2;          // sign(7)  = -
-                z[8] = s3;    z[9] = wpk_add(s3, s4);     z[10] = wpk_sub(s3, s4);    z[11] = s4;         // sign(11) = -
-                z[12] = d[2]; z[13] = wpk_add(d[2], d[3]); z[14] = wpk_sub(d[2], d[3]); z[15] = d[3];     // sign(12,13,14) = -
-                dbacc[c] = wpk_add(dbacc[c], wpk_add(z[1], z[13]));
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int x = 0; x < 16; ++x)
-                        acc[x][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x][h], z[x][h], acc[x][c], 0, 0, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
+            v[4 * i + 0] = wpk_sub(t0, t2);
+            v[4 * i + 1] = wpk_add(t1, t2);
+            v[4 * i + 2] = wpk_sub(t2, t1);
+            v[4 * i + 3] = wpk_sub(t1, t3);
         }
     };
-
+    // Z = A dY A^T up to signs (applied in the reduce) for tile pair pr, cj block c; dY = [[a, b], [c, d]] = d[0..3]
+    auto load_z = [&](int buf, int pr, int c, f32x2 (&z)[16]) {
+        const unsigned char *ys = smem + buf * WW_STAGE + y_base + (2 * wj + c) * 1024 + (kg + 8 * pr) * 64;
+        f32x2 d[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            d[px][0] = *(const float *)(ys + px * 4096);
+            d[px][1] = *(const float *)(ys + px * 4096 + 256);
+        }
+        const f32x2 s1 = wpk_add(d[0], d[2]), s2 = wpk_add(d[1], d[3]);
+        const f32x2 s3 = wpk_sub(d[0], d[2]), s4 = wpk_sub(d[1], d[3]);
+        z[0] = d[0];  z[1] = wpk_add(d[0], d[1]); z[2] = wpk_sub(d[0], d[1]); z[3] = d[1];        // sign(3)  = -
+        z[4] = s1;    z[5] = wpk_add(s1, s2);     z[6] = wpk_sub(s1, s2);     z[7] = s2;          // sign(7)  = -
+        z[8] = s3;    z[9] = wpk_add(s3, s4);     z[10] = wpk_sub(s3, s4);    z[11] = s4;         // sign(11) = -
+        z[12] = d[2]; z[13] = wpk_add(d[2], d[3]); z[14] = wpk_sub(d[2], d[3]); z[15] = d[3];     // sign(12,13,14) = -
+        dbacc[c] = wpk_add(dbacc[c], wpk_add(z[1], z[13]));
+    };
+    auto mfma32 = [&](const f32x2 (&v)[16], const f32x2 (&z)[16], int c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                acc[x][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x][h], z[x][h], acc[x][c], 0, 0, 0);
+    };
     // ---- pipeline: stage s+2 is issued at the start of step s (into the buffer step s-1 freed); at the end of step s
     // everything but that batch has landed -> stage s+1.
     if (ns > 0) {
@@ -258,10 +268,38 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
         if (ns > 1) stage(1, s0 + 1);
         wait_landed(ns > 1);
         __builtin_amdgcn_s_barrier();
+        // the two waves of a SIMD (w, w+4) issue their LDS-DMA batch half a step apart: one wave's ~200-cycle-per-
+        // instruction issue then overlaps the partner's MFMAs
+        const bool early = wave < 4;
         for (int s = 0; s < ns; ++s) {
-            const bool more = s + 2 < ns;
-            if (more) stage((s + 2) % WW_NST, s0 + s + 2);
-            compute(s % WW_NST);
+            const bool more = s + 2 < ns && DBG != 1;
+            const int buf = s % WW_NST;
+            if (more && early) stage((s + 2) % WW_NST, s0 + s + 2);
+            if (DBG != 2) {
+                // software pipeline inside the step: the operands of the next 32 MFMAs are read and transformed in the
+                // shadow of the current 32 (each MFMA leaves 24 of its 32 cycles of vector issue free)
+                f32x2 va[16], vb[16], za[16], zb[16];
+                load_v(buf, 0, va);
+                load_z(buf, 0, 0, za);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma32(va, za, 0);
+                load_z(buf, 0, 1, zb);
+                if (SCHED) ww_interleave<18, 1, 0>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma32(va, zb, 1);
+                load_v(buf, 1, vb);
+                if (SCHED) ww_interleave<32, 1, 1>();
+                __builtin_amdgcn_sched_barrier(0);
+                load_z(buf, 1, 0, za);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma32(vb, za, 0);
+                load_z(buf, 1, 1, zb);
+                if (SCHED) ww_interleave<18, 1, 0>();
+                __builtin_amdgcn_sched_barrier(0);
+                mfma32(vb, zb, 1);
+            } else if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
             wait_landed(more);
             __builtin_amdgcn_s_barrier();
         }
@@ -391,8 +429,10 @@ double wgrad_alg_flops_pub(const WgradP &p);
 
 int launch_wgradw(const WgradP &p, hipStream_t st)
 {
-    static bool attr_done[64] = {false};
-    if (int rc_ = ensure_dynamic_lds((const void *)wgradw_f32_kernel, WW_LDS, attr_done)) return rc_;
+    static const int dbg = [] { const char *e = getenv("UNET_WW_DBG"); return e ? atoi(e) : 0; }();
+    auto kern = dbg == 1 ? wgradw_f32_kernel<1, false> : dbg == 2 ? wgradw_f32_kernel<2, false> : dbg == 3 ? wgradw_f32_kernel<0, true> : wgradw_f32_kernel<0, false>;
+    static bool attr_done[4][64] = {{false}};
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, WW_LDS, attr_done[dbg >= 1 && dbg <= 3 ? dbg : 0])) return rc_;
     WgradWK k;
     int cus = ww_cus();
     if (cus > 256) cus = 256;
@@ -406,7 +446,7 @@ int launch_wgradw(const WgradP &p, hipStream_t st)
     char tag[96];
     snprintf(tag, sizeof(tag), "wgradw Ci=%d Cj=%d Y=%dx%d tiles=%dx%d steps=%d split=%d", p.Ci, p.Cj, p.YH, p.YW, k.TYn, k.TXn, k.nsteps, k.nsplit);
     prof_begin(1, wgrad_alg_flops_pub(p), st, tag);
-    hipLaunchKernelGGL(wgradw_f32_kernel, dim3(ntile * k.nsplit), dim3(512), WW_LDS, st, k);
+    hipLaunchKernelGGL(kern, dim3(ntile * k.nsplit), dim3(512), WW_LDS, st, k);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     prof_begin(2, 0.0, st);

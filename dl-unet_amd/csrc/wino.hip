@@ -134,7 +134,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
     return a - b;
 }
 
-template <int DBG, bool PERSIST>
+template <int DBG>
 __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
 {
     const IgemmP &p = k.p;
@@ -148,14 +148,11 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     const int ns = k.nsteps;
     const bool early = wave < 4;
 
-    // ---- persistent workgroups: one per CU, each walks the (N tile, M tile) list with stride gridDim.x.  Within a
-    // pass every XCD (blockIdx & 7) gets a contiguous run of logical tiles; M tiles of one N tile are neighbours
-    // (they share the 32 KiB/step U stream, twice the patch bytes).
-    const int G = gridDim.x;
-    const int total = p.mtiles * p.ntiles;
+    // ---- one (N tile, M tile) per workgroup.  XCD-aware order: every XCD (blockIdx & 7) gets a contiguous run of logical
+    // tiles; M tiles of one N tile are neighbours (they share the 32 KiB/step U stream, twice the patch bytes).
     int slot;
     {
-        const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
+        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
 
@@ -268,7 +265,7 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     };
 
     f32x4 acc[16][2];
-    f32x2 v0[16], v1[16];
+    f32x2 v0[16];
     f32x4 bf[2][2];
 
     // A pixels of a step -> V, column by column (B^T d on the 4 pixels of a column as they arrive, then (.) B per row
@@ -321,14 +318,15 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     // ---- main loop of one tile, one barrier per step (at its end).  Batch of step s = patches(s+3) + U(s+2), into the
     // buffers step s-1 freed.  During step s a wave also reads and transforms the A pixels of step s+1 (landed since
     // the previous barrier).  End of step s: everything but this step's batch has landed -> U(s+1), patches(s+2).
-    // The two waves of a SIMD (w and w+4) run complementary schedules so that one wave's LDS-DMA issue (~200 cycles
-    // per instruction) and transform hide behind the partner's MFMAs:
-    //                   early (waves 0-3): batch, transform(s+1), 64 MFMAs
+    // The two waves of a SIMD (w and w+4) issue their batch half a step apart, so that one wave's LDS-DMA issue (~200
+    // cycles per instruction) hides behind the partner's MFMAs:
+    //                   early (waves 0-3): batch, 64 MFMAs, transform(s+1)
     //                   late  (waves 4-7): 32 MFMAs, batch, 32 MFMAs, transform(s+1)
     // Each role is its own copy of the loop (one uniform branch around the whole loop, none inside a step).
     auto run = [&](auto role) {
         constexpr bool EARLY = decltype(role)::value;
-        auto step = [&](int s, const f32x2 (&vc)[16], f32x2 (&vn)[16]) {
+        // one V array: the transform of step s+1 overwrites it once all MFMAs of step s have issued
+        auto step1 = [&](int s) {
             int kind = 0;
             const int ub = s % WINO_NST;
             auto batch = [&]() {
@@ -338,31 +336,20 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
                 }
             };
             read_b(ub, 0);
-            if (EARLY) {
-                batch();
-                if (s + 1 < ns) load_v(vn, (s + 1) % WINO_NST);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_combos(vc, ub, 0, 8);
-            } else {
-                mfma_combos(vc, ub, 0, 4);
-                batch();
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_combos(vc, ub, 4, 8);
-                if (s + 1 < ns) load_v(vn, (s + 1) % WINO_NST);
-            }
+            if (EARLY) batch();
+            mfma_combos(v0, ub, 0, 4);
+            if (!EARLY) batch();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_combos(v0, ub, 4, 8);
+            if (s + 1 < ns) load_v(v0, (s + 1) % WINO_NST);
             wait_landed(kind);
             __builtin_amdgcn_s_barrier();
         };
-        int s = 0;
-        for (; s + 1 < ns; s += 2) {
-            step(s, v0, v1);
-            step(s + 1, v1, v0);
-        }
-        if (s < ns) step(s, v0, v1);
+        for (int s = 0; s < ns; ++s) step1(s);
     };
 
     // ---- epilogue of the tile (T0c, n0c), two passes (channels 32*pass..+31: the waves with wn == pass write) through a
-    // 32 KiB staging image in U buffer 2 — the next tile's first stages are already in flight in the other buffers.
+    // 32 KiB staging image in U buffer 2.
     //   staging[256 rows = tile*4 + 2*py + px][32 n] floats | rowoff[256] | flags[256] (after the rings)
     float *stg = (float *)(smem + WINO_UBASE + 2 * 32768);
     unsigned *rowoff = (unsigned *)(smem + WINO_LDS);
@@ -460,38 +447,22 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
         }
     };
 
-    // ---- tile loop
-    int logical = slot;
-    if (logical >= total) return;
-    setup_tile(logical);
+    // ---- the tile
+    setup_tile(slot);
     for (int i = 0; i < 3; ++i) issue_patch();          // ns >= 4 (every source has >= 32 channels)
     stage_u(0, 0);
     stage_u(1, 1);
-    while (true) {
 #pragma unroll
-        for (int x = 0; x < 16; ++x)
+    for (int x = 0; x < 16; ++x)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
-        wino_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        load_v(v0, 0);
-        if (early) run(std::true_type{}); else run(std::false_type{});
-        // every wave is past the last step's barrier: the rings are free.  Start the next tile's first stages, then
-        // drain this tile's accumulators while they fly.
-        const int T0c = T0, n0c = n0;
-        const int next = PERSIST ? logical + G : total;     // !PERSIST: one tile per workgroup
-        if (next < total) {
-            setup_tile(next);
-            for (int i = 0; i < 3; ++i) issue_patch();
-            stage_u(0, 0);
-            stage_u(1, 1);
-        }
-        epilogue(T0c, n0c);
-        if (next >= total) break;
-        logical = next;
-    }
+            for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
+    wino_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_v(v0, 0);
+    if (early) run(std::true_type{}); else run(std::false_type{});
+    epilogue(T0, n0);
 }
 
 double igemm_alg_flops(const IgemmP &p);
@@ -512,15 +483,10 @@ size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * Nn; }
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
 {
     static const int dbg = [] { const char *e = getenv("UNET_WINO_DBG"); return e ? atoi(e) : 0; }();
-    static const int persist = [] { const char *e = getenv("UNET_WINO_PERSIST"); return e ? atoi(e) : 0; }();
-    auto kern = dbg == 1 ? wino_f32_kernel<1, false> : persist ? wino_f32_kernel<0, true> : wino_f32_kernel<0, false>;
-    static bool attr_done[64] = {false}, attr_done1[64] = {false}, attr_done2[64] = {false};
+    auto kern = dbg == 1 ? wino_f32_kernel<1> : wino_f32_kernel<0>;
+    static bool attr_done[64] = {false}, attr_done1[64] = {false};
     constexpr int LDS = WINO_LDS + 1280 + 3 * 512 * 4;          // rings + the epilogue's row tables + parked second-source offsets
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, dbg == 1 ? attr_done1 : persist ? attr_done2 : attr_done)) return rc_;
-    static int ncu[64] = {0};
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (!ncu[dev]) HIP_TRY(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, dbg == 1 ? attr_done1 : attr_done)) return rc_;
     WinoP q;
     q.p = p;
     q.U = U;
@@ -535,7 +501,7 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     q.p.mtiles = cdiv(q.MT, 64);
     q.p.ntiles = p.Nn / 64;
     const int total = q.p.mtiles * q.p.ntiles;
-    const int grid = (!persist || total < ncu[dev]) ? total : ncu[dev];       // persist: one 512-thread workgroup per CU walks the tiles
+    const int grid = total;
     char tag[96];
     snprintf(tag, sizeof(tag), "wino M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
     prof_begin(3, igemm_alg_flops(p), st, tag);
