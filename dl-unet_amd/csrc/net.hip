@@ -67,6 +67,9 @@ using namespace unet;
 struct unet_handle {
     int base_ch;
     int device;
+    // backward: the weight gradients run on an auxiliary stream next to the dgrad chain (they only share dz)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // plans of the training forwards still awaiting their backward, keyed by workspace pointer
     std::mutex mu;
     std::vector<std::pair<void *, Plan>> live;
@@ -348,6 +351,11 @@ int unet_create(unet_handle **out, const unet_config *cfg)
 
 int unet_destroy(unet_handle *h)
 {
+    if (h) {
+        if (h->aux) (void)hipStreamDestroy(h->aux);
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    }
     delete h;
     return 0;
 }
@@ -527,21 +535,45 @@ int unet_backward_stage_params(int stage, int *idx, int cap)
 
 #define GRAD(i) ((float *)grads[(i)])
 
-static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const void *const *params, void *const *grads,
+// Weight gradients of a backward stage go to `wst()`: the handle's auxiliary stream, made to wait for everything enqueued
+// on the main stream so far (dz is ready), or the main stream itself when overlap is off.
+struct WgradStream {
+    unet_handle *h; hipStream_t main; bool overlap; bool used = false;
+    hipStream_t operator()()
+    {
+        if (!overlap) return main;
+        (void)hipEventRecord(h->ev_fork, main);
+        (void)hipStreamWaitEvent(h->aux, h->ev_fork, 0);
+        used = true;
+        return h->aux;
+    }
+    void join()
+    {
+        if (!used) return;
+        (void)hipEventRecord(h->ev_join, h->aux);
+        (void)hipStreamWaitEvent(main, h->ev_join, 0);
+        used = false;
+    }
+};
+
+static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, WgradStream &wst, const void *const *params, void *const *grads,
                          int layer, const float *X, int XH, int C, const float *dz, int Ho, int K,
                          float *dx, const float *mask, const float *add)
 {
-    // single-source 3x3 conv: dgrad (optional), wgrad, bias grad
+    // single-source 3x3 conv: wgrad + bias grad (auxiliary stream), dgrad (optional)
     const int B = pl.B;
     int rc;
+    {
+        WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes, GRAD(2 * layer + 1));
+        if ((rc = launch_wgrad(w, wst()))) return rc;
+    }
     if (dx) {
         if ((rc = pack_conv_dgrad(PARAM(2 * layer), WS(pl.wt_bwd[layer]), K, C, st))) return rc;
         IgemmP d = conv_dgrad_desc(dz, Ho, Ho, K, B, XH, 0, WS(pl.wt_bwd[layer]), C, dx, mask, add);
         if ((rc = with_wino(d, WS(pl.wu_bwd[layer]), st))) return rc;
         if ((rc = launch_igemm(d, st))) return rc;
     }
-    WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes, GRAD(2 * layer + 1));
-    return launch_wgrad(w, st);
+    return 0;
 }
 
 int unet_backward_stage(unet_handle *h, int stage, const void *const *params, const void *dlogits, void *const *grads,
@@ -560,6 +592,15 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
     const int B = pl.B;
     const int *ch = pl.ch;
     int rc;
+    static const int overlap = [] { const char *e = getenv("UNET_OVERLAP"); return e ? atoi(e) : 0; }();   // opt-in: +1 %
+    if (overlap && !h->aux) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    WgradStream wst{h, st, overlap != 0};
+    struct Joiner { WgradStream &w; ~Joiner() { w.join(); } } joiner{wst};      // every return path re-joins the streams
 
     if (stage < 4) {
         const int l = stage;
@@ -570,7 +611,7 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
                                        GRAD(2 * FINAL), GRAD(2 * FINAL + 1), WS(pl.small), stream))) return rc;
         }
         // conv_l2e: input d1[l] (ReLU output of conv_l1e)
-        if ((rc = conv_backward(pl, workspace, st, params, grads, C2E_L[l], WS(pl.d1[l]), pl.ed1[l], ch[l], WS(pl.g_d2[l]), pl.ed2[l], ch[l],
+        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, C2E_L[l], WS(pl.d1[l]), pl.ed1[l], ch[l], WS(pl.g_d2[l]), pl.ed2[l], ch[l],
                                 WS(pl.g_d1[l]), WS(pl.d1[l]), nullptr))) return rc;
         // conv_l1e: virtual concat input.  dgrad per source half (skip half only over the crop window)
         const int lay = C1E_L[l];
@@ -588,10 +629,10 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
         {
             WgradP ws_ = conv_wgrad_desc(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
                                          GRAD(2 * lay), 2 * ch[l], 0, WS(pl.slab), pl.slab_bytes);
-            if ((rc = launch_wgrad(ws_, st))) return rc;
+            if ((rc = launch_wgrad(ws_, wst()))) return rc;
             WgradP wu = conv_wgrad_desc(WS(pl.u[l]), pl.eu[l], ch[l], 0, WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
                                         GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes, GRAD(2 * lay + 1));
-            if ((rc = launch_wgrad(wu, st))) return rc;
+            if ((rc = launch_wgrad(wu, wst()))) return rc;
         }
         // upconv_l: input is d2[l+1] (or a2[4]); its dgrad is masked by that ReLU output
         {
@@ -609,28 +650,28 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             d.mask = uin;
             if ((rc = launch_igemm(d, st))) return rc;
             WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes, GRAD(2 * ul + 1));
-            if ((rc = launch_wgrad(w, st))) return rc;
+            if ((rc = launch_wgrad(w, wst()))) return rc;
         }
         return 0;
     }
 
     if (stage == 4) {
-        if ((rc = conv_backward(pl, workspace, st, params, grads, C52C, WS(pl.a1[4]), pl.ea1[4], ch[4], WS(pl.g_a2[4]), pl.ea2[4], ch[4],
+        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, C52C, WS(pl.a1[4]), pl.ea1[4], ch[4], WS(pl.g_a2[4]), pl.ea2[4], ch[4],
                                 WS(pl.g_a1[4]), WS(pl.a1[4]), nullptr))) return rc;
-        if ((rc = conv_backward(pl, workspace, st, params, grads, C51C, WS(pl.t[3]), pl.ein[4], ch[3], WS(pl.g_a1[4]), pl.ea1[4], ch[4],
+        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, C51C, WS(pl.t[3]), pl.ein[4], ch[3], WS(pl.g_a1[4]), pl.ea1[4], ch[4],
                                 WS(pl.g_t[3]), nullptr, WS(pl.g_ts[3])))) return rc;
         return unet_maxpool2_bwd(WS(pl.a2[3]), WS(pl.g_t[3]), WS(pl.g_a2[3]), B, pl.ea2[3], pl.ea2[3], ch[3], stream);
     }
 
     // stage 5: encoder levels 3..0
     for (int l = 3; l >= 0; --l) {
-        if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l + 1, WS(pl.a1[l]), pl.ea1[l], ch[l], WS(pl.g_a2[l]), pl.ea2[l], ch[l],
+        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, 2 * l + 1, WS(pl.a1[l]), pl.ea1[l], ch[l], WS(pl.g_a2[l]), pl.ea2[l], ch[l],
                                 WS(pl.g_a1[l]), WS(pl.a1[l]), nullptr))) return rc;
         if (l == 0) {
             // conv11c: weight/bias gradient only (A1 needs no dgrad)
             return unet_conv1ch_bwd(WS(pl.xin), B, pl.S, ch[0], WS(pl.g_a1[0]), GRAD(0), GRAD(1), WS(pl.small), stream);
         }
-        if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l, WS(pl.t[l - 1]), pl.ein[l], ch[l - 1], WS(pl.g_a1[l]), pl.ea1[l], ch[l],
+        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, 2 * l, WS(pl.t[l - 1]), pl.ein[l], ch[l - 1], WS(pl.g_a1[l]), pl.ea1[l], ch[l],
                                 WS(pl.g_t[l - 1]), nullptr, WS(pl.g_ts[l - 1])))) return rc;
         if ((rc = unet_maxpool2_bwd(WS(pl.a2[l - 1]), WS(pl.g_t[l - 1]), WS(pl.g_a2[l - 1]), B, pl.ea2[l - 1], pl.ea2[l - 1], ch[l - 1], stream))) return rc;
     }
