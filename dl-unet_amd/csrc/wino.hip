@@ -315,6 +315,73 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
         }
     };
 
+    // combos 4..7 (xi 8..15) of a step with the transform of the NEXT step's V rows 0,1 (xi 0..7, whose MFMAs of this
+    // step have all issued) in their shadow: pixel reads one combo ahead of the adds that consume them.  NXT = false
+    // for the last step.  V rows 2,3 follow after the last MFMA (they are still operands until then).
+    auto mfma8 = [&](int c) {
+        const int xg = c >> 1, h = c & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[4 * xg + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[4 * xg + e][h], bf[c & 1][0][e], acc[4 * xg + e][0], 0, 0, 0);
+            acc[4 * xg + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[4 * xg + e][h], bf[c & 1][1][e], acc[4 * xg + e][1], 0, 0, 0);
+        }
+    };
+    auto second_half = [&](int ub, int pb, auto nxt_tag) {
+        constexpr bool NXT = decltype(nxt_tag)::value;
+        const unsigned char *sa = smem + pb * WINO_PATCH + offA;
+        const unsigned char *sb = smem + pb * WINO_PATCH + offB;
+        f32x2 r0[3], r1[3], tl[2][4];
+        auto rd = [&](int j, f32x2 (&r)[3]) {
+            const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW;
+            r[0] = *(const f32x2 *)(src);
+            r[1] = *(const f32x2 *)(src + 2 * WINO_ROW);
+            r[2] = *(const f32x2 *)(src + 4 * WINO_ROW);
+        };
+        auto col = [&](int j, const f32x2 (&r)[3]) { tl[0][j] = pk_sub(r[0], r[2]); tl[1][j] = pk_add(r[1], r[2]); };
+        read_b(ub, 5);
+        if (NXT) { rd(0, r0); rd(1, r1); }
+        mfma8(4);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(ub, 6);
+        mfma8(5);
+        if (NXT) { col(0, r0); col(1, r1); rd(2, r0); rd(3, r1); }
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(ub, 7);
+        mfma8(6);
+        if (NXT) {
+            col(2, r0); col(3, r1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v0[4 * i + 0] = pk_sub(tl[i][0], tl[i][2]);
+                v0[4 * i + 1] = pk_add(tl[i][1], tl[i][2]);
+                v0[4 * i + 2] = pk_sub(tl[i][2], tl[i][1]);
+                v0[4 * i + 3] = pk_sub(tl[i][1], tl[i][3]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(7);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NXT) {
+            // V rows 2,3 from pixel rows 1,2,3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW + 2 * WINO_ROW;
+                const f32x2 a1 = *(const f32x2 *)(src);
+                const f32x2 a2 = *(const f32x2 *)(src + 2 * WINO_ROW);
+                const f32x2 a3 = *(const f32x2 *)(src + 4 * WINO_ROW);
+                tl[0][j] = pk_sub(a2, a1);
+                tl[1][j] = pk_sub(a1, a3);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v0[8 + 4 * i + 0] = pk_sub(tl[i][0], tl[i][2]);
+                v0[8 + 4 * i + 1] = pk_add(tl[i][1], tl[i][2]);
+                v0[8 + 4 * i + 2] = pk_sub(tl[i][2], tl[i][1]);
+                v0[8 + 4 * i + 3] = pk_sub(tl[i][1], tl[i][3]);
+            }
+        }
+    };
+
     // ---- main loop of one tile, one barrier per step (at its end).  Batch of step s = patches(s+3) + U(s+2), into the
     // buffers step s-1 freed.  During step s a wave also reads and transforms the A pixels of step s+1 (landed since
     // the previous barrier).  End of step s: everything but this step's batch has landed -> U(s+1), patches(s+2).
@@ -326,7 +393,8 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     auto run = [&](auto role) {
         constexpr bool EARLY = decltype(role)::value;
         // one V array: the transform of step s+1 overwrites it once all MFMAs of step s have issued
-        auto step1 = [&](int s) {
+        auto step1 = [&](int s, auto last_tag) {
+            constexpr bool last = decltype(last_tag)::value;
             int kind = 0;
             const int ub = s % WINO_NST;
             auto batch = [&]() {
@@ -340,12 +408,13 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
             mfma_combos(v0, ub, 0, 4);
             if (!EARLY) batch();
             __builtin_amdgcn_sched_barrier(0);
-            mfma_combos(v0, ub, 4, 8);
-            if (s + 1 < ns) load_v(v0, (s + 1) % WINO_NST);
+            if (last) second_half(ub, 0, std::false_type{});
+            else second_half(ub, (s + 1) % WINO_NST, std::true_type{});
             wait_landed(kind);
             __builtin_amdgcn_s_barrier();
         };
-        for (int s = 0; s < ns; ++s) step1(s);
+        for (int s = 0; s + 1 < ns; ++s) step1(s, std::false_type{});
+        step1(ns - 1, std::true_type{});
     };
 
     // ---- epilogue of the tile (T0c, n0c), two passes (channels 32*pass..+31: the waves with wn == pass write) through a
