@@ -534,6 +534,284 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     epilogue(T0, n0);
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Half-width variant: 256 threads = 64 tiles x 32 output channels, 2-deep rings (68 KiB) -> TWO workgroups per CU.
+// The workgroups of a CU are independent, so one's set-up, first-stage latency, epilogue and barrier stalls hide behind
+// the other's MFMAs, and a launch has twice as many, half as heavy workgroups (finer last round).  The price: the
+// patch image is staged once per 32 instead of per 64 output channels (34 instead of 25 LDS-DMA instructions per
+// 64x32x8 block of work).  Chosen per launch by launch_wino (short K loops and badly filled last rounds).
+constexpr int W32_UBASE = 2 * WINO_PATCH;                 // 36864
+constexpr int W32_LDS = W32_UBASE + 2 * 16384;            // 69632
+constexpr int W32_TOTAL = W32_LDS + 1280 + 5 * 256 * 4;   // + row tables + parked second-source offsets = 76032
+
+__global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
+{
+    const IgemmP &p = k.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = wm: tiles 16*wave .. +15, all 32 channels
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int tpi = k.tiles_x * k.tiles_y;
+    const int ns = k.nsteps;
+
+    int slot;
+    {
+        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int nt = slot / p.mtiles, mt = slot - nt * p.mtiles;
+    const int T0 = mt * 64, n0 = nt * 32;
+    const int R0 = fdiv(T0, k.d_tx);
+
+    // ---- DMA role: patch instructions i = wave + 4*ii (i < 18): 5 for waves 0,1, 4 for waves 2,3; U pieces 4*wave .. +3
+    constexpr int NPI = 5;
+    const int npi = wave < 2 ? 5 : 4;
+    int poff[NPI];
+    int *poff1 = (int *)(smem + W32_LDS + 1280) + tid;
+#pragma unroll
+    for (int ii = 0; ii < NPI; ++ii) {
+        const int pos = (wave + 4 * ii) * 1024 + lane * 16;
+        const int row = pos / WINO_ROW;
+        const int rem = pos - row * WINO_ROW;
+        const int idx = rem >> 5;
+        const int qy = row >> 1, par = row & 1, half = ((rem >> 4) & 1) ^ ((idx >> 3) & 1);
+        int T, qx;
+        bool ok = true;
+        if (idx < 64) {
+            T = T0 + idx; qx = par;
+        } else {
+            const int j = idx - 64;
+            ok = (R0 + j) * k.tiles_x <= T0 + 63;
+            T = (R0 + j + 1) * k.tiles_x - 1;
+            T = T < T0 + 63 ? T : T0 + 63;
+            qx = 2 + par;
+        }
+        T = T < k.MT ? T : k.MT - 1;
+        const int img = fdiv(T, k.d_tpi);
+        const int trem = T - img * tpi;
+        const int ty = fdiv(trem, k.d_tx);
+        const int tx = trem - ty * k.tiles_x;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            int o = -1;
+            if (si < p.nsrc && ii < npi) {
+                const GSrc &g = p.src[si];
+                const int iy = 2 * ty + p.oy0 - g.pad + qy, ix = 2 * tx + p.ox0 - g.pad + qx;
+                const bool inb = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                o = inb ? ((img * g.H + iy) * g.W + ix) * g.C + g.c0 + 4 * half : -1;
+            }
+            if (si == 0) poff[ii] = o; else if (p.nsrc > 1) poff1[ii * 256] = o;
+        }
+    }
+    const float *sp = p.src[0].p;
+    int snch = p.src[0].nch, kc = 0, pissued = 0;
+    // U: the 32 channels are half (nt & 1) of the 64-channel block nt >> 1
+    const float *ublk = k.U + (size_t)(nt >> 1) * ns * 8192 + (nt & 1) * 4096 + (4 * wave) * 256 + lane * 4;
+
+    const int tl = wave * 16 + l15;
+    const int offA = tl * 32 + (((kg >> 1) ^ ((tl >> 3) & 1)) * 16) + (kg & 1) * 8;
+    int offB;
+    {
+        const int T = T0 + tl;
+        const int R = fdiv(T, k.d_tx);
+        const bool rowend = (T - R * k.tiles_x == k.tiles_x - 1) || tl == 63;
+        int j = R - R0;
+        j = j < 7 ? j : 7;
+        const int idxB = rowend ? 64 + j : tl + 1;
+        offB = idxB * 32 + (((kg >> 1) ^ ((idxB >> 3) & 1)) * 16) + (kg & 1) * 8;
+    }
+    const int b_rd = W32_UBASE + lane * 16;
+
+    // one stage = this wave's patch instructions + its 4 U pieces (9 or 8 LDS-DMA instructions)
+    auto issue_stage = [&]() {
+        const int buf = pissued & 1;
+        unsigned char *sb = smem + buf * WINO_PATCH + wave * 1024;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const float *g = poff[ii] >= 0 ? sp + (poff[ii] + kc) : p.zeros;
+            GLDS16(g, sb + ii * 4096);
+        }
+        if (wave < 2) {
+            const float *g = poff[4] >= 0 ? sp + (poff[4] + kc) : p.zeros;
+            GLDS16(g, sb + 16384);
+        }
+        unsigned char *ub = smem + W32_UBASE + buf * 16384 + (4 * wave) * 1024;
+        const float *us = ublk + (size_t)pissued * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
+        ++pissued;
+        kc += 8;
+        if (kc == snch && pissued < ns) {
+            kc = 0;
+            sp = p.src[1].p; snch = p.src[1].nch;
+#pragma unroll
+            for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff1[ii * 256];
+        }
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
+    f32x2 v0[16];
+    f32x4 bf[2][2];
+
+    auto load_v = [&](int buf) {
+        const unsigned char *sa = smem + buf * WINO_PATCH + offA;
+        const unsigned char *sb = smem + buf * WINO_PATCH + offB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW;
+            const f32x2 a0 = *(const f32x2 *)(src);
+            const f32x2 a1 = *(const f32x2 *)(src + 2 * WINO_ROW);
+            const f32x2 a2 = *(const f32x2 *)(src + 4 * WINO_ROW);
+            const f32x2 a3 = *(const f32x2 *)(src + 6 * WINO_ROW);
+            v0[j] = pk_sub(a0, a2);
+            v0[4 + j] = pk_add(a1, a2);
+            v0[8 + j] = pk_sub(a2, a1);
+            v0[12 + j] = pk_sub(a1, a3);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 t0 = v0[4 * i], t1 = v0[4 * i + 1], t2 = v0[4 * i + 2], t3 = v0[4 * i + 3];
+            v0[4 * i + 0] = pk_sub(t0, t2);
+            v0[4 * i + 1] = pk_add(t1, t2);
+            v0[4 * i + 2] = pk_sub(t2, t1);
+            v0[4 * i + 3] = pk_sub(t1, t3);
+        }
+    };
+    auto read_b = [&](int buf, int c) {
+        const unsigned char *sb = smem + buf * 16384 + b_rd;
+        bf[c & 1][0] = *(const f32x4 *)(sb + c * 1024);
+        bf[c & 1][1] = *(const f32x4 *)(sb + 8192 + c * 1024);
+    };
+
+    // ---- pipeline (2-deep): stages s, s+1 in flight at most.  Step s: 64 MFMAs from U(s); wait stage s+1, barrier (every
+    // wave is done with U(s) and, since the previous step, with patches(s)); issue stage s+2 into the freed buffers;
+    // transform patches(s+1).
+    issue_stage();
+    issue_stage();                                    // ns >= 4
+    if (wave < 2) wino_wait_vmcnt<9>(); else wino_wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    load_v(0);
+    for (int s = 0; s < ns; ++s) {
+        const int ub = s & 1;
+        read_b(ub, 0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int xg = c >> 1, h = c & 1;
+            if (c + 1 < 8) read_b(ub, c + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[4 * xg + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[4 * xg + e][h], bf[c & 1][0][e], acc[4 * xg + e][0], 0, 0, 0);
+                acc[4 * xg + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[4 * xg + e][h], bf[c & 1][1][e], acc[4 * xg + e][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wino_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < ns) issue_stage();
+        if (s + 1 < ns) load_v((s + 1) & 1);
+    }
+    __syncthreads();
+
+    // ---- epilogue: staging[256 rows = tile*4 + 2*py + px][32 n] in the U ring | rowoff[256] | flags[256]
+    float *stg = (float *)(smem + W32_UBASE);
+    unsigned *rowoff = (unsigned *)(smem + W32_LDS);
+    unsigned char *rflag = smem + W32_LDS + 1024;
+    {
+        const int tl2 = tid >> 2, py = (tid >> 1) & 1, px = tid & 1;
+        int T = T0 + tl2;
+        const bool tok = T < k.MT;
+        T = tok ? T : k.MT - 1;
+        const int img = fdiv(T, k.d_tpi);
+        const int rem = T - img * tpi;
+        const int ty = fdiv(rem, k.d_tx);
+        const int tx = rem - ty * k.tiles_x;
+        int oy = 2 * ty + py, ox = 2 * tx + px;
+        const bool ok = tok && oy < p.OH && ox < p.OW;
+        oy = oy < p.OH ? oy : p.OH - 1; ox = ox < p.OW ? ox : p.OW - 1;
+        unsigned off;
+        if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
+        else off = (unsigned)((img * p.OH + oy) * p.OW + ox) * (unsigned)p.DC;
+        rowoff[tid] = off;
+        const bool inwin = (p.rw1 > p.rw0) && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
+        rflag[tid] = (ok ? 0 : 1) | (inwin ? 2 : 0);
+    }
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        const int n = nn * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = acc[j][nn][r] + acc[4 + j][nn][r] + acc[8 + j][nn][r];
+                s1[j] = acc[4 + j][nn][r] - acc[8 + j][nn][r] - acc[12 + j][nn][r];
+            }
+            const int tile = wave * 16 + 4 * kg + r;
+            float *o = stg + (tile * 4) * 32 + n;
+            o[0] = s0[0] + s0[1] + s0[2];
+            o[32] = s0[1] - s0[2] - s0[3];
+            o[64] = s1[0] + s1[1] + s1[2];
+            o[96] = s1[1] - s1[2] - s1[3];
+        }
+    }
+    __syncthreads();
+    const bool relu_win = p.rw1 > p.rw0;
+    const int c4 = tid & 7;
+    const int ncol = n0 + 4 * c4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = p.bias[p.cout ? n % p.cout : n]; }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it += 4) {
+        f32x4 v[4];
+        size_t o[4];
+        unsigned char fl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = (it + u) * 32 + (tid >> 3);
+            v[u] = *(const f32x4 *)(stg + row * 32 + 4 * c4) + bv;
+            o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
+            fl[u] = rflag[row];
+        }
+        if (p.add) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.add + o[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += t[u];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool defer = relu_win && (fl[u] & 2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] > 0.f || defer) ? v[u][c] : 0.f;
+            }
+        }
+        if (p.mask) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.mask + o[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[u][c] = t[u][c] > 0.f ? v[u][c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (!(fl[u] & 1)) *(f32x4 *)(p.dst + o[u]) = v[u];
+    }
+}
+
 double igemm_alg_flops(const IgemmP &p);
 
 bool wino_applicable(const IgemmP &p)
@@ -569,6 +847,31 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     q.d_tx = make_fastdiv((unsigned)q.tiles_x);
     q.p.mtiles = cdiv(q.MT, 64);
     q.p.ntiles = p.Nn / 64;
+    // variant: 0 = 512 threads x (64 tiles x 64 n), 1 = 256 threads x (64 tiles x 32 n), two per CU (UNET_WINO32: -1 auto)
+    // Measured over the net's 42 launches: the half-width variant wins whenever the K loop is short (its two
+    // independent workgroups per CU hide each other's fixed costs) or the 64-wide launch would end in a small partial
+    // round; the 64-wide one wins for >= 64 steps with a full or more than half-full last round.
+    static const int force32 = [] { const char *e = getenv("UNET_WINO32"); return e ? atoi(e) : -1; }();
+    static int ncu[64] = {0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!ncu[dev]) HIP_TRY(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    const int total64 = q.p.mtiles * q.p.ntiles;
+    const int rem64 = total64 % ncu[dev];
+    const bool wide = q.nsteps >= 64 && (rem64 == 0 || 2 * rem64 >= ncu[dev]);
+    const bool half = force32 >= 0 ? force32 != 0 : !wide;
+    if (half && dbg != 1) {
+        static bool attr32[64] = {false};
+        if (int rc_ = ensure_dynamic_lds((const void *)wino32_f32_kernel, W32_TOTAL, attr32)) return rc_;
+        q.p.ntiles = p.Nn / 32;
+        char tag32[96];
+        snprintf(tag32, sizeof(tag32), "wino32 M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
+        prof_begin(3, igemm_alg_flops(p), st, tag32);
+        hipLaunchKernelGGL(wino32_f32_kernel, dim3(q.p.mtiles * q.p.ntiles), dim3(256), W32_TOTAL, st, q);
+        prof_end(st);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int total = q.p.mtiles * q.p.ntiles;
     const int grid = total;
     char tag[96];

@@ -20,7 +20,7 @@ def run(B, H, C, K, mode, reps=10):
     torch.cuda.synchronize()
     import ctypes as C_
     ms = C_.c_double(); n = C_.c_long(); fl = C_.c_double()
-    L.unet_profile_read(0, C_.byref(ms), C_.byref(n), C_.byref(fl))
+    L.unet_profile_read(3, C_.byref(ms), C_.byref(n), C_.byref(fl))
     L.unet_profile_enable(0)
     return ms.value / max(n.value, 1)
 
