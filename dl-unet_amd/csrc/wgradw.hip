@@ -42,6 +42,7 @@ struct WgradWK {
     int ntile_i, ntile_j, nsplit;
     FastDiv d_spi, d_txg;     // slots per image, slots per row
     size_t pstride;           // floats per slab
+    int xbytes, ybytes;       // buffer-descriptor sizes of X and Y (bytes); the buffer path needs both below 2 GiB
 };
 
 constexpr int WW_PATCH = 32768, WW_EXTRA = 2048, WW_DY = 16384;
@@ -84,7 +85,7 @@ template <int N, int VALU_, int DS_> __device__ __forceinline__ void ww_interlea
     }
 }
 
-template <int DBG, bool SCHED>
+template <int DBG, bool SCHED, bool BUF>
 __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
 {
     const WgradP &p = k.p;
@@ -115,6 +116,11 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     const int d_cb = wave & 3, d_par = (wave >> 2) & 1;
     const int spi = k.TYn * k.TXg;
 
+    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): 32-bit byte offsets, the row offset as
+    // scalar offset, pixels outside the tensors as offsets beyond num_records (the range check returns zeros).
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.X, 0, BUF ? k.xbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)p.Y, 0, BUF ? k.ybytes : 0, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
     auto stage = [&](int buf, int step) {
         unsigned char *sb = smem + buf * WW_STAGE;
         // the lane-derived roles are recomputed per call (a handful of VALU) instead of living in VGPRs across the loop:
@@ -139,8 +145,13 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
 #pragma unroll
             for (int qy = 0; qy < 4; ++qy) {
                 const bool ok = xok && (unsigned)(iy0 + qy) < (unsigned)p.XH;
-                const float *g = ok ? p.X + (base + qy * p.XW * p.XC) : p.zeros;
-                GLDS16(g, sb + ((qy * 2 + d_par) * 4 + d_cb) * 1024);
+                unsigned char *dst = sb + ((qy * 2 + d_par) * 4 + d_cb) * 1024;
+                if (BUF) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)dst, 16, ok ? (base + qy * p.XW * p.XC) * 4 : OOB, 0, 0, 0);      // (base alone can be negative under zero padding)
+                } else {
+                    const float *g = ok ? p.X + (base + qy * p.XW * p.XC) : p.zeros;
+                    GLDS16(g, dst);
+                }
             }
         }
         // dz: pixel (py, px = d_par) of the slot; ghost slots and pixels outside the tensor read zeros
@@ -151,8 +162,13 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 const bool ok = xok && yy0 + py < p.YH;
-                const float *g = ok ? p.Y + (base + py * p.YW * p.YC) : p.zeros;
-                GLDS16(g, sb + WW_PATCH + WW_EXTRA + ((py * 2 + d_par) * 4 + d_cb) * 1024);
+                unsigned char *dst = sb + WW_PATCH + WW_EXTRA + ((py * 2 + d_par) * 4 + d_cb) * 1024;
+                if (BUF) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (__attribute__((address_space(3))) void *)dst, 16, ok ? (base + py * p.YW * p.YC) * 4 : OOB, 0, 0, 0);
+                } else {
+                    const float *g = ok ? p.Y + (base + py * p.YW * p.YC) : p.zeros;
+                    GLDS16(g, dst);
+                }
             }
         }
         if (wave < 2) {
@@ -170,8 +186,13 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
             const int qy = e_row >> 1, par = e_row & 1;
             const int iy = (k.wy0 + 2 * ety + p.oy0) - p.xpad + qy, ix = (k.wx0 + 2 * etxg + p.ox0) - p.xpad + par;
             const bool ok = eok && (unsigned)iy < (unsigned)p.XH && (unsigned)ix < (unsigned)p.XW;
-            const float *g = ok ? p.X + (((eimg * p.XH + iy) * p.XW + ix) * p.XC + e_xch) : p.zeros;
-            GLDS16(g, sb + WW_PATCH + wave * 1024);
+            const int eoff = ((eimg * p.XH + iy) * p.XW + ix) * p.XC + e_xch;
+            if (BUF) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + WW_PATCH + wave * 1024), 16, ok ? eoff * 4 : OOB, 0, 0, 0);
+            } else {
+                const float *g = ok ? p.X + eoff : p.zeros;
+                GLDS16(g, sb + WW_PATCH + wave * 1024);
+            }
         }
     };
     // wait until only the newest batch (one stage) of this wave is still in flight, or nothing
@@ -430,13 +451,18 @@ double wgrad_alg_flops_pub(const WgradP &p);
 int launch_wgradw(const WgradP &p, hipStream_t st)
 {
     static const int dbg = [] { const char *e = getenv("UNET_WW_DBG"); return e ? atoi(e) : 0; }();
-    auto kern = dbg == 1 ? wgradw_f32_kernel<1, false> : dbg == 2 ? wgradw_f32_kernel<2, false> : dbg == 3 ? wgradw_f32_kernel<0, true> : wgradw_f32_kernel<0, false>;
-    static bool attr_done[4][64] = {{false}};
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, WW_LDS, attr_done[dbg >= 1 && dbg <= 3 ? dbg : 0])) return rc_;
+    static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
+    const size_t xb = (size_t)p.NB * p.XH * p.XW * p.XC * sizeof(float), yb = (size_t)p.NB * p.YH * p.YW * p.YC * sizeof(float);
+    const bool buf = usebuf && xb < 0x7FFFFFFFull && yb < 0x7FFFFFFFull;
+    auto kern = dbg == 1 ? wgradw_f32_kernel<1, false, false> : dbg == 2 ? wgradw_f32_kernel<2, false, false> : dbg == 3 ? wgradw_f32_kernel<0, true, false>
+              : buf ? wgradw_f32_kernel<0, false, true> : wgradw_f32_kernel<0, false, false>;
+    static bool attr_done[5][64] = {{false}};
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, WW_LDS, attr_done[dbg >= 1 && dbg <= 3 ? dbg : buf ? 4 : 0])) return rc_;
     WgradWK k;
     int cus = ww_cus();
     if (cus > 256) cus = 256;
     ww_decompose(p, k, cus);
+    k.xbytes = buf ? (int)xb : 0; k.ybytes = buf ? (int)yb : 0;
     const int ntile = k.ntile_i * k.ntile_j;
     const size_t need = (size_t)ntile * k.nsplit * k.pstride * sizeof(float);
     ARG_CHECK(need <= p.slab_bytes, "wgradw: slab scratch too small (%zu < %zu)", p.slab_bytes, need);

@@ -45,6 +45,7 @@ struct WinoP {
     int MT;                  // NB * tiles_y * tiles_x
     int nsteps;              // total channels / 8
     FastDiv d_tpi, d_tx;
+    int xbytes[2], ubytes;   // buffer-descriptor sizes (bytes) of the sources and of U; 0 if any exceeds 2 GiB
 };
 
 
@@ -134,7 +135,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
     return a - b;
 }
 
-template <int DBG>
+template <int DBG, bool BUF>
 __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
 {
     const IgemmP &p = k.p;
@@ -213,6 +214,10 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
                 if (si == 0) poff[ii] = o; else if (p.nsrc > 1) poff1[ii * 512] = o;
             }
         }
+        if (BUF) {
+#pragma unroll
+            for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff[ii] >= 0 ? poff[ii] * 4 : (int)0x80000000;
+        }
         sp = p.src[0].p; snch = p.src[0].nch; kc = 0; pissued = 0;
         ublk = k.U + (size_t)nt * ns * 8192 + (4 * wave) * 256 + lane * 4;
         {
@@ -227,8 +232,21 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     };
 
     // Per batch a wave issues 2 (+1 for waves 0,1) patch instructions and 4 U instructions: the vmcnt waits count on it.
+    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): fixed per-lane byte offsets, the channel
+    // step in the scalar offset, out-of-tensor pixels as offsets beyond num_records (zeros) - no per-step address VALU.
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, BUF ? k.xbytes[0] : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)k.U, 0, BUF ? k.ubytes : 0, 0x00020000);
+    const int u_voff = ((4 * wave) * 256 + lane * 4) * 4;
     auto stage_patch = [&](int buf, int kch) {
         unsigned char *sb = smem + buf * WINO_PATCH + wave * 1024;
+        if (BUF) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + ii * 8192), 16, poff[ii], kch * 4, 0, 0);
+            if (wave < 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + 16384), 16, poff[2], kch * 4, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const float *g = poff[ii] >= 0 ? sp + (poff[ii] + kch) : p.zeros;
@@ -241,6 +259,13 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
     };
     auto stage_u = [&](int buf, int step) {
         unsigned char *ub = smem + WINO_UBASE + buf * 32768 + (4 * wave) * 1024;
+        if (BUF) {
+            const int us = ((n0 >> 6) * ns + step) * 32768;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(ub + i * 1024), 16, u_voff, us + i * 1024, 0, 0);
+            return;
+        }
         const float *us = ublk + (size_t)step * 8192;
 #pragma unroll
         for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
@@ -252,8 +277,9 @@ __global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
         if (kc == snch && pissued < ns) {
             kc = 0;
             sp = p.src[1].p; snch = p.src[1].nch;
+            if (BUF) rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[1].p, 0, k.xbytes[1], 0x00020000);
 #pragma unroll
-            for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff1[ii * 512];
+            for (int ii = 0; ii < NPI; ++ii) { const int o = poff1[ii * 512]; poff[ii] = BUF ? (o >= 0 ? o * 4 : (int)0x80000000) : o; }
         }
     };
     // wait until only the newest batch of this wave is still in flight: kind 0 = nothing issued in it, 1 = U only, 2 = patch + U
@@ -544,6 +570,7 @@ constexpr int W32_UBASE = 2 * WINO_PATCH;                 // 36864
 constexpr int W32_LDS = W32_UBASE + 2 * 16384;            // 69632
 constexpr int W32_TOTAL = W32_LDS + 1280 + 5 * 256 * 4;   // + row tables + parked second-source offsets = 76032
 
+template <bool BUF>
 __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
 {
     const IgemmP &p = k.p;
@@ -608,6 +635,17 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     int snch = p.src[0].nch, kc = 0, pissued = 0;
     // U: the 32 channels are half (nt & 1) of the 64-channel block nt >> 1
     const float *ublk = k.U + (size_t)(nt >> 1) * ns * 8192 + (nt & 1) * 4096 + (4 * wave) * 256 + lane * 4;
+    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane byte offset is fixed for the
+    // whole tile, the channel step goes into the scalar offset, and pixels outside the tensor are offsets beyond
+    // num_records (the range check returns zeros) - no per-step address VALU at all.  Needs tensors < 2 GiB.
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, BUF ? k.xbytes[0] : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)k.U, 0, BUF ? k.ubytes : 0, 0x00020000);
+    const int u_voff = ((4 * wave) * 256 + lane * 4) * 4;
+    const int u_soff0 = ((nt >> 1) * ns * 8192 + (nt & 1) * 4096) * 4;
+    if (BUF) {
+#pragma unroll
+        for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff[ii] >= 0 ? poff[ii] * 4 : (int)0x80000000;
+    }
 
     const int tl = wave * 16 + l15;
     const int offA = tl * 32 + (((kg >> 1) ^ ((tl >> 3) & 1)) * 16) + (kg & 1) * 8;
@@ -627,26 +665,39 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     auto issue_stage = [&]() {
         const int buf = pissued & 1;
         unsigned char *sb = smem + buf * WINO_PATCH + wave * 1024;
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const float *g = poff[ii] >= 0 ? sp + (poff[ii] + kc) : p.zeros;
-            GLDS16(g, sb + ii * 4096);
-        }
-        if (wave < 2) {
-            const float *g = poff[4] >= 0 ? sp + (poff[4] + kc) : p.zeros;
-            GLDS16(g, sb + 16384);
-        }
         unsigned char *ub = smem + W32_UBASE + buf * 16384 + (4 * wave) * 1024;
-        const float *us = ublk + (size_t)pissued * 8192;
+        if (BUF) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
+            for (int ii = 0; ii < 4; ++ii)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + ii * 4096), 16, poff[ii], kc * 4, 0, 0);
+            if (wave < 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + 16384), 16, poff[4], kc * 4, 0, 0);
+            const int us = u_soff0 + pissued * 32768;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(ub + i * 1024), 16, u_voff, us + i * 1024, 0, 0);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const float *g = poff[ii] >= 0 ? sp + (poff[ii] + kc) : p.zeros;
+                GLDS16(g, sb + ii * 4096);
+            }
+            if (wave < 2) {
+                const float *g = poff[4] >= 0 ? sp + (poff[4] + kc) : p.zeros;
+                GLDS16(g, sb + 16384);
+            }
+            const float *us = ublk + (size_t)pissued * 8192;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
+        }
         ++pissued;
         kc += 8;
         if (kc == snch && pissued < ns) {
             kc = 0;
             sp = p.src[1].p; snch = p.src[1].nch;
+            if (BUF) rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[1].p, 0, k.xbytes[1], 0x00020000);
 #pragma unroll
-            for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff1[ii * 256];
+            for (int ii = 0; ii < NPI; ++ii) { const int o = poff1[ii * 256]; poff[ii] = BUF ? (o >= 0 ? o * 4 : (int)0x80000000) : o; }
         }
     };
 
@@ -830,10 +881,7 @@ size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * Nn; }
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
 {
     static const int dbg = [] { const char *e = getenv("UNET_WINO_DBG"); return e ? atoi(e) : 0; }();
-    auto kern = dbg == 1 ? wino_f32_kernel<1> : wino_f32_kernel<0>;
-    static bool attr_done[64] = {false}, attr_done1[64] = {false};
     constexpr int LDS = WINO_LDS + 1280 + 3 * 512 * 4;          // rings + the epilogue's row tables + parked second-source offsets
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, dbg == 1 ? attr_done1 : attr_done)) return rc_;
     WinoP q;
     q.p = p;
     q.U = U;
@@ -860,18 +908,38 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     const int rem64 = total64 % ncu[dev];
     const bool wide = q.nsteps >= 64 && (rem64 == 0 || 2 * rem64 >= ncu[dev]);
     const bool half = force32 >= 0 ? force32 != 0 : !wide;
+    // buffer-descriptor LDS-DMA needs every tensor below 2 GiB (32-bit num_records and the out-of-range marker)
+    static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
+    bool buf = usebuf != 0;
+    {
+        const size_t ub = wino_u_floats(kc, p.Nn) * sizeof(float);
+        if (ub >= 0x7FFFFFFFull) buf = false;
+        q.ubytes = (int)ub;
+        for (int i = 0; i < 2; ++i) {
+            q.xbytes[i] = 0;
+            if (i < p.nsrc) {
+                const size_t xb = (size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C * sizeof(float);
+                if (xb >= 0x7FFFFFFFull) buf = false;
+                q.xbytes[i] = (int)xb;
+            }
+        }
+    }
     if (half && dbg != 1) {
-        static bool attr32[64] = {false};
-        if (int rc_ = ensure_dynamic_lds((const void *)wino32_f32_kernel, W32_TOTAL, attr32)) return rc_;
+        static bool attr32[64] = {false}, attr32b[64] = {false};
+        auto k32 = buf ? wino32_f32_kernel<true> : wino32_f32_kernel<false>;
+        if (int rc_ = ensure_dynamic_lds((const void *)k32, W32_TOTAL, buf ? attr32b : attr32)) return rc_;
         q.p.ntiles = p.Nn / 32;
         char tag32[96];
         snprintf(tag32, sizeof(tag32), "wino32 M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
         prof_begin(3, igemm_alg_flops(p), st, tag32);
-        hipLaunchKernelGGL(wino32_f32_kernel, dim3(q.p.mtiles * q.p.ntiles), dim3(256), W32_TOTAL, st, q);
+        hipLaunchKernelGGL(k32, dim3(q.p.mtiles * q.p.ntiles), dim3(256), W32_TOTAL, st, q);
         prof_end(st);
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    auto kern = dbg == 1 ? wino_f32_kernel<1, false> : buf ? wino_f32_kernel<0, true> : wino_f32_kernel<0, false>;
+    static bool attr_done[64] = {false}, attr_done1[64] = {false}, attr_doneb[64] = {false};
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, dbg == 1 ? attr_done1 : buf ? attr_doneb : attr_done)) return rc_;
     const int total = q.p.mtiles * q.p.ntiles;
     const int grid = total;
     char tag[96];
