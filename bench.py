@@ -175,7 +175,7 @@ def main():
             if os.path.exists(tpath) and B == B_PER_GPU:
                 traffic = json.load(open(tpath)).get("%s_hbm_mb_per_launch" % dom.split("_")[0])
                 traffic = traffic * 1e6 if traffic else None
-            kname = {"wino_f32": "wino_f32_kernel (3x3 conv fwd / dgrad, Winograd F(2x2,3x3) on the fp32 MFMA)",
+            kname = {"wino_f32": "wino_f32_kernel / wino32_f32_kernel (3x3 conv fwd / dgrad, Winograd F(2x2,3x3) on the fp32 MFMA)",
                      "igemm_f32": "igemm_f32_kernel (conv fwd / dgrad / up-conv implicit GEMM)"}[dom]
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -13,10 +13,11 @@ def short(n):
     return n.split("(")[0].replace("void ", "").replace("unet::", "")[:44]
 
 stats = list(csv.DictReader(open("profiles/%s_rocprofv3_kernel_stats.csv" % tag)))
-DOM = (("wino", "wino_f32_kernel"), ("igemm", "igemm_f32_kernel"))     # kernels whose traffic / launch time are reported
+DOM = (("wino", "wino"), ("igemm", "igemm_f32_kernel"))     # kernels whose traffic / launch time are reported ("wino": wino_f32_kernel + wino32_f32_kernel)
+EXCL = ("wino_transform",)
 calls = {}; ns = {}
 for key, sub in DOM:
-    rs = [r for r in stats if sub in r["Name"]]
+    rs = [r for r in stats if sub in r["Name"] and not any(e in r["Name"] for e in EXCL)]
     calls[key] = sum(int(r["Calls"]) for r in rs); ns[key] = sum(float(r["TotalDurationNs"]) for r in rs)
 
 def counters(sub):
@@ -39,7 +40,7 @@ lines = ["# %s — rocprofv3 PMC summary (bench.py --steps 2 --warmup 1, separat
          "| kernel | launches | ms total | clock GHz | MFMA busy | WAIT_ANY/WAVE | fetch MB/launch (x2) | write MB/launch | LDS bank-conflict cycles / LDS active |",
          "|---|---|---|---|---|---|---|---|---|"]
 tot_f = collections.Counter(); tot_w = collections.Counter(); tot_n = collections.Counter()
-for k in sorted(dur, key=lambda k: -dur[k])[:14]:
+for k in sorted(dur, key=lambda k: -dur[k])[:24]:
     c = sq[k]; clk = c["GRBM_GUI_ACTIVE"] / 8 / dur[k] if dur[k] else 0
     busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * dur[k] * clk) if clk else 0
     f = 2 * fe[k]["FETCH_SIZE"] / 1024 / max(nfe[k], 1); w = wr[k]["WRITE_SIZE"] / 1024 / max(nwr[k], 1)
@@ -47,7 +48,7 @@ for k in sorted(dur, key=lambda k: -dur[k])[:14]:
     lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.3f |" % (k, nsq[k], dur[k] / 1e6, clk, busy,
                  c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), f, w, lb))
     for key, sub in DOM:
-        if sub in k:
+        if sub in k and not any(e in k for e in EXCL):
             tot_f[key] += 2 * fe[k]["FETCH_SIZE"] / 1024; tot_w[key] += wr[k]["WRITE_SIZE"] / 1024; tot_n[key] += nfe[k]
 out = {"source": "profiles/%s_pmc_summary.md" % tag}
 lines.append("")
