@@ -101,6 +101,7 @@ int launch_igemm(IgemmP p, hipStream_t st);
 bool wino_applicable(const IgemmP &p);
 size_t wino_u_floats(int Kc, int Nn);
 int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *U, hipStream_t st);
+int wino_transform_ref(const float *w_oihw, int I, int dgrad, int n0, int Nn, int k0, int Kc, float *U, hipStream_t st);
 int get_math_mode();
 void set_math_mode(int m);
 

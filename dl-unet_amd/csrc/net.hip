@@ -131,11 +131,31 @@ static size_t layer_wino_floats(int base, int layer)
     return layer_numel(base, layer, false) / 9 * 16;
 }
 
-// math mode 3: transform this launch's packed filters into `wu` and route the launch to wino.hip
-static int with_wino(IgemmP &p, float *wu, hipStream_t st)
+// One 3x3 layer's reference (OIHW) weights and their packed igemm copy.  The copy is made on first need: in math mode 3
+// most launches take the Winograd path, whose filter transform reads the reference weights directly.
+struct WLayer {
+    const float *w; int O, I;      // reference tensor [O][I][3][3]
+    bool dgrad;                    // packed copy: forward [O][9*(C1|C2)] or dgrad [I][9*O]
+    float *wt; int C1, C2;
+    bool packed = false;
+    int ensure_packed(hipStream_t st)
+    {
+        if (packed) return 0;
+        packed = true;
+        return dgrad ? pack_conv_dgrad(w, wt, O, I, st) : pack_conv_fwd(w, wt, O, C1, C2, st);
+    }
+};
+static WLayer wl_fwd(const float *w, int K, int C1, int C2, float *wt) { return WLayer{w, K, C1 + C2, false, wt, C1, C2}; }
+static WLayer wl_dgrad(const float *w, int K, int C, float *wt) { return WLayer{w, K, C, true, wt, 0, 0}; }
+
+// Route a 3x3 launch: math mode 3 and a shape wino.hip takes -> transform the filters (rows n0.., columns k0.. of the
+// launch's filter matrix within the layer) into `wu`; otherwise make sure the packed igemm weights exist.
+static int with_wino(IgemmP &p, float *wu, WLayer &L, int n0, int k0, hipStream_t st)
 {
-    if (get_math_mode() != 3 || !wu || !wino_applicable(p)) return 0;
-    int rc = wino_transform(p.wt, p.ldw ? p.ldw : p.Kd, p.Nn, p.src[0].nch, p.nsrc > 1 ? p.src[1].nch : 0, wu, st);
+    if (get_math_mode() != 3 || !wu || !wino_applicable(p)) return L.ensure_packed(st);
+    int kc = 0;
+    for (int i = 0; i < p.nsrc; ++i) kc += p.src[i].nch;
+    int rc = wino_transform_ref(L.w, L.I, L.dgrad ? 1 : 0, n0, p.Nn, k0, kc, wu, st);
     if (rc) return rc;
     p.wino_u = wu;
     return 0;
@@ -173,9 +193,10 @@ static IgemmP conv_fwd_desc(const float *x1, int H1, int W1, int C1, int pad1, c
 // window), launch 2 = skip source over the window only, accumulating in place (+ReLU).  Same math, same
 // K order per source; the two partial sums are added in fp32.
 static int conv_fwd_launch(const float *x1, int H1, int C1, int pad1, const float *x2, int C2, int B, int H,
-                           const float *wt, const float *bias, int K, int relu, float *y, hipStream_t st, float *wu = nullptr)
+                           WLayer &L, const float *bias, int K, int relu, float *y, hipStream_t st, float *wu = nullptr)
 {
     const int Ho = H - 2;
+    const float *wt = L.wt;
     int rc;
     int w0 = pad1 - 2; if (w0 < 0) w0 = 0;
     int w1 = pad1 + H1; if (w1 > Ho) w1 = Ho;
@@ -183,21 +204,21 @@ static int conv_fwd_launch(const float *x1, int H1, int C1, int pad1, const floa
     const bool split = x2 && pad1 > 0 && (double)(w1 - w0) * (w1 - w0) < split_thr * (double)Ho * Ho;
     if (!split) {
         IgemmP p = conv_fwd_desc(x1, H1, H1, C1, pad1, x2, x2 ? C2 : 0, B, H, H, wt, bias, K, relu, y);
-        if ((rc = with_wino(p, wu, st))) return rc;
+        if ((rc = with_wino(p, wu, L, 0, 0, st))) return rc;
         return launch_igemm(p, st);
     }
     const int ldw = 9 * (C1 + C2);
     IgemmP a = conv_fwd_desc(x2, H, H, C2, 0, nullptr, 0, B, H, H, wt + 9 * C1, bias, K, relu, y);
     a.ldw = ldw;
     if (relu) { a.rw0 = w0; a.rw1 = w1; }
-    if ((rc = with_wino(a, wu, st))) return rc;
+    if ((rc = with_wino(a, wu, L, 0, C1, st))) return rc;
     if ((rc = launch_igemm(a, st))) return rc;
     IgemmP b = conv_fwd_desc(x1, H1, H1, C1, pad1, nullptr, 0, B, H, H, wt, nullptr, K, relu, y);
     b.ldw = ldw;
     b.OH = b.OW = w1 - w0; b.M = B * b.OH * b.OW; b.oy0 = b.ox0 = w0;
     b.scatter = 2; b.dwy0 = b.dwx0 = w0; b.DH = b.DW = Ho;
     b.add = y;
-    if ((rc = with_wino(b, wu ? wu + wino_u_floats(C2, K) : nullptr, st))) return rc;
+    if ((rc = with_wino(b, wu ? wu + wino_u_floats(C2, K) : nullptr, L, 0, 0, st))) return rc;
     return launch_igemm(b, st);
 }
 
@@ -420,15 +441,9 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
     const int *ch = pl.ch;
 
     // repack the parameters (reference layout, owned by the caller and updated by its optimizer)
-    for (int l = 1; l < 5; ++l) {
-        if ((rc = pack_conv_fwd(PARAM(2 * (2 * l)), WS(pl.wt_fwd[2 * l]), ch[l], ch[l - 1], 0, st))) return rc;
-    }
-    for (int l = 0; l < 5; ++l)
-        if ((rc = pack_conv_fwd(PARAM(2 * (2 * l + 1)), WS(pl.wt_fwd[2 * l + 1]), ch[l], ch[l], 0, st))) return rc;
+    // (the 3x3 layers' weights are packed lazily, only if a launch of the layer takes the implicit-GEMM path: with_wino)
     for (int l = 0; l < 4; ++l) {
         if ((rc = pack_upconv_fwd(PARAM(2 * UP_L[l]), WS(pl.wt_fwd[UP_L[l]]), ch[l + 1], ch[l], st))) return rc;
-        if ((rc = pack_conv_fwd(PARAM(2 * C1E_L[l]), WS(pl.wt_fwd[C1E_L[l]]), ch[l], ch[l], ch[l], st))) return rc;
-        if ((rc = pack_conv_fwd(PARAM(2 * C2E_L[l]), WS(pl.wt_fwd[C2E_L[l]]), ch[l], ch[l], 0, st))) return rc;
     }
 
     // encoder (network.py:131-156); the input is kept for conv11c's weight gradient
@@ -438,12 +453,14 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
         if (l > 0) {
             IgemmP p = conv_fwd_desc(WS(pl.t[l - 1]), pl.ein[l], pl.ein[l], ch[l - 1], 0, nullptr, 0, B, pl.ein[l], pl.ein[l],
                                      WS(pl.wt_fwd[2 * l]), PARAM(2 * (2 * l) + 1), ch[l], 1, WS(pl.a1[l]));
-            if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l]), st))) return rc;
+            WLayer L = wl_fwd(PARAM(2 * (2 * l)), ch[l], ch[l - 1], 0, WS(pl.wt_fwd[2 * l]));
+            if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l]), L, 0, 0, st))) return rc;
             if ((rc = launch_igemm(p, st))) return rc;
         }
         IgemmP p = conv_fwd_desc(WS(pl.a1[l]), pl.ea1[l], pl.ea1[l], ch[l], 0, nullptr, 0, B, pl.ea1[l], pl.ea1[l],
                                  WS(pl.wt_fwd[2 * l + 1]), PARAM(2 * (2 * l + 1) + 1), ch[l], 1, WS(pl.a2[l]));
-        if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l + 1]), st))) return rc;
+        WLayer L2 = wl_fwd(PARAM(2 * (2 * l + 1)), ch[l], ch[l], 0, WS(pl.wt_fwd[2 * l + 1]));
+        if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l + 1]), L2, 0, 0, st))) return rc;
         if ((rc = launch_igemm(p, st))) return rc;
         if (l < 4 && (rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
     }
@@ -459,11 +476,13 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
         u.dst = WS(pl.u[l]); u.DH = pl.eu[l]; u.DW = pl.eu[l]; u.DC = ch[l]; u.scatter = 1; u.cout = ch[l];
         u.bias = PARAM(2 * UP_L[l] + 1);
         if ((rc = launch_igemm(u, st))) return rc;
+        WLayer L1 = wl_fwd(PARAM(2 * C1E_L[l]), ch[l], ch[l], ch[l], WS(pl.wt_fwd[C1E_L[l]]));
         if ((rc = conv_fwd_launch(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l],
-                                  WS(pl.wt_fwd[C1E_L[l]]), PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st, WS(pl.wu_fwd[C1E_L[l]])))) return rc;
+                                  L1, PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st, WS(pl.wu_fwd[C1E_L[l]])))) return rc;
         IgemmP c2 = conv_fwd_desc(WS(pl.d1[l]), pl.ed1[l], pl.ed1[l], ch[l], 0, nullptr, 0, B, pl.ed1[l], pl.ed1[l],
                                   WS(pl.wt_fwd[C2E_L[l]]), PARAM(2 * C2E_L[l] + 1), ch[l], 1, WS(pl.d2[l]));
-        if ((rc = with_wino(c2, WS(pl.wu_fwd[C2E_L[l]]), st))) return rc;
+        WLayer L2e = wl_fwd(PARAM(2 * C2E_L[l]), ch[l], ch[l], 0, WS(pl.wt_fwd[C2E_L[l]]));
+        if ((rc = with_wino(c2, WS(pl.wu_fwd[C2E_L[l]]), L2e, 0, 0, st))) return rc;
         if ((rc = launch_igemm(c2, st))) return rc;
         dsrc = WS(pl.d2[l]);
     }
@@ -568,9 +587,9 @@ static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, WgradS
         if ((rc = launch_wgrad(w, wst()))) return rc;
     }
     if (dx) {
-        if ((rc = pack_conv_dgrad(PARAM(2 * layer), WS(pl.wt_bwd[layer]), K, C, st))) return rc;
+        WLayer L = wl_dgrad(PARAM(2 * layer), K, C, WS(pl.wt_bwd[layer]));
         IgemmP d = conv_dgrad_desc(dz, Ho, Ho, K, B, XH, 0, WS(pl.wt_bwd[layer]), C, dx, mask, add);
-        if ((rc = with_wino(d, WS(pl.wu_bwd[layer]), st))) return rc;
+        if ((rc = with_wino(d, WS(pl.wu_bwd[layer]), L, 0, 0, st))) return rc;
         if ((rc = launch_igemm(d, st))) return rc;
     }
     return 0;
@@ -615,15 +634,15 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
                                 WS(pl.g_d1[l]), WS(pl.d1[l]), nullptr))) return rc;
         // conv_l1e: virtual concat input.  dgrad per source half (skip half only over the crop window)
         const int lay = C1E_L[l];
-        if ((rc = pack_conv_dgrad(PARAM(2 * lay), WS(pl.wt_bwd[lay]), ch[l], 2 * ch[l], st))) return rc;
+        WLayer Ld = wl_dgrad(PARAM(2 * lay), ch[l], 2 * ch[l], WS(pl.wt_bwd[lay]));
         {
             IgemmP ds = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.et[l], pl.pad[l],
                                         WS(pl.wt_bwd[lay]), ch[l], WS(pl.g_ts[l]), nullptr, nullptr);
-            if ((rc = with_wino(ds, WS(pl.wu_bwd[lay]), st))) return rc;
+            if ((rc = with_wino(ds, WS(pl.wu_bwd[lay]), Ld, 0, 0, st))) return rc;
             if ((rc = launch_igemm(ds, st))) return rc;
             IgemmP du = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.eu[l], 0,
                                         WS(pl.wt_bwd[lay]) + (size_t)ch[l] * 9 * ch[l], ch[l], WS(pl.g_u[l]), nullptr, nullptr);
-            if ((rc = with_wino(du, WS(pl.wu_bwd[lay]) + wino_u_floats(ch[l], ch[l]), st))) return rc;
+            if ((rc = with_wino(du, WS(pl.wu_bwd[lay]) + wino_u_floats(ch[l], ch[l]), Ld, ch[l], 0, st))) return rc;
             if ((rc = launch_igemm(du, st))) return rc;
         }
         {
@@ -710,11 +729,10 @@ int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
     ARG_CHECK(x1 && w_oihw && y && scratch, "conv3x3_fwd: null argument");
     ARG_CHECK(x2 || (H1 + 2 * pad1 == H && W1 + 2 * pad1 == W), "conv3x3_fwd: single source must match the input extent");
     hipStream_t st = (hipStream_t)stream;
-    int rc = pack_conv_fwd((const float *)w_oihw, (float *)scratch, K, C1, x2 ? C2 : 0, st);
-    if (rc) return rc;
     ARG_CHECK(H == W && H1 == W1, "conv3x3_fwd: square tiles only");
+    WLayer L = wl_fwd((const float *)w_oihw, K, C1, x2 ? C2 : 0, (float *)scratch);
     float *wu = (float *)((char *)scratch + align_up((size_t)K * (C1 + (x2 ? C2 : 0)) * 9 * sizeof(float), 256));
-    return conv_fwd_launch((const float *)x1, H1, C1, pad1, (const float *)x2, x2 ? C2 : 0, B, H, (const float *)scratch,
+    return conv_fwd_launch((const float *)x1, H1, C1, pad1, (const float *)x2, x2 ? C2 : 0, B, H, L,
                            (const float *)bias, K, relu, (float *)y, st, wu);
 }
 
@@ -741,15 +759,15 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
     float *wu = (float *)((char *)scratch + wt_bytes + slab_bytes + align_up(bias_grad_scratch_bytes((size_t)B * Ho * Ho, K), 256));
     int rc;
     if (dx1 || dx2) {
-        if ((rc = pack_conv_dgrad((const float *)w_oihw, wt, K, C, st))) return rc;
+        WLayer L = wl_dgrad((const float *)w_oihw, K, C, wt);
         if (dx1) {
             IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H1, pad1, wt, C1, (float *)dx1, (const float *)mask1, (const float *)add1);
-            if ((rc = with_wino(d, wu, st))) return rc;
+            if ((rc = with_wino(d, wu, L, 0, 0, st))) return rc;
             if ((rc = launch_igemm(d, st))) return rc;
         }
         if (dx2 && x2) {
             IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H, 0, wt + (size_t)C1 * 9 * K, C2, (float *)dx2, (const float *)mask2, nullptr);
-            if ((rc = with_wino(d, wu + wino_u_floats(K, C1), st))) return rc;
+            if ((rc = with_wino(d, wu + wino_u_floats(K, C1), L, C1, 0, st))) return rc;
             if ((rc = launch_igemm(d, st))) return rc;
         }
     }

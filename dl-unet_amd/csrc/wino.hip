@@ -96,6 +96,60 @@ __global__ __launch_bounds__(256) void wino_transform_kernel(const float *__rest
     }
 }
 
+// The same U, straight from the reference's OIHW weights (no packed copy needed):
+//   forward  (dgrad = 0): filter matrix row n = output channel n0 + n, column k = input channel k0 + k, taps as stored
+//   dgrad    (dgrad = 1): row n = INPUT channel n0 + n, column k = output channel k0 + k, taps flipped (index 8 - t)
+// Thread order keeps the 36-byte reads of neighbouring threads adjacent (k fastest forward, n fastest dgrad).
+__global__ __launch_bounds__(256) void wino_transform_ref_kernel(const float *__restrict__ w, int I, int dgrad, int n0, int Nn, int k0, int Kc,
+                                                                 float *__restrict__ U)
+{
+    const size_t total = (size_t)Nn * Kc;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int n, c;
+    if (dgrad) { c = (int)(idx / Nn); n = (int)(idx - (size_t)c * Nn); }
+    else       { n = (int)(idx / Kc); c = (int)(idx - (size_t)n * Kc); }
+    const int o = dgrad ? k0 + c : n0 + n, i = dgrad ? n0 + n : k0 + c;
+    const float *src = w + ((size_t)o * I + i) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = src[dgrad ? 8 - t : t];
+    float r[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        r[0][j] = g[0][j];
+        r[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        r[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        r[3][j] = g[2][j];
+    }
+    float u[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[4 * a + 0] = r[a][0];
+        u[4 * a + 1] = 0.5f * (r[a][0] + r[a][1] + r[a][2]);
+        u[4 * a + 2] = 0.5f * (r[a][0] - r[a][1] + r[a][2]);
+        u[4 * a + 3] = r[a][2];
+    }
+    const int nsteps = Kc >> 3;
+    const int nt = n >> 6, n16 = (n >> 4) & 3, nl = n & 15;
+    const int step = c >> 3, kk = c & 7, kg = kk >> 1, h = kk & 1;
+    float *blk = U + ((size_t)nt * nsteps + step) * 8192;
+#pragma unroll
+    for (int xg = 0; xg < 4; ++xg) {
+        f32x4 v = {u[4 * xg], u[4 * xg + 1], u[4 * xg + 2], u[4 * xg + 3]};
+        *(f32x4 *)(blk + ((n16 * 4 + xg) * 2 + h) * 256 + (kg * 16 + nl) * 4) = v;
+    }
+}
+
+int wino_transform_ref(const float *w_oihw, int I, int dgrad, int n0, int Nn, int k0, int Kc, float *U, hipStream_t st)
+{
+    ARG_CHECK(w_oihw && U && Nn % 64 == 0 && Kc % 8 == 0 && Kc > 0, "wino_transform_ref: bad shape");
+    const size_t total = (size_t)Nn * Kc;
+    hipLaunchKernelGGL(wino_transform_ref_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, I, dgrad, n0, Nn, k0, Kc, U);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *U, hipStream_t st)
 {
     ARG_CHECK(wt && U && Nn % 64 == 0 && nch0 % 8 == 0 && nch1 % 8 == 0 && nch0 > 0, "wino_transform: bad shape");
