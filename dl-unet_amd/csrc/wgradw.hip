@@ -130,13 +130,16 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
         const int d_slot = ln >> 2, d_chunk = ln & 3;
         const int xch = p.xc0 + it * 64 + d_cb * 16 + d_chunk * 4;
         const int ych = p.yc0 + jt * 64 + d_cb * 16 + d_chunk * 4;
-        const int T = step * 16 + d_slot;
-        const bool tok = T < k.NTg;
-        const int Tc = tok ? T : k.NTg - 1;
-        const int img = fdiv(Tc, k.d_spi);
-        const int rem = Tc - img * spi;
-        const int ty = fdiv(rem, k.d_txg);
-        const int txg = rem - ty * k.TXg;
+        // the step's first slot is decomposed once, on the scalar unit (uniform); a lane then only walks d_slot slots on
+        const int Tb = step * 16;
+        const bool tok = Tb + d_slot < k.NTg;
+        const int img_b = fdiv(Tb, k.d_spi);
+        const int rem_b = Tb - img_b * spi;
+        const int ty_b = fdiv(rem_b, k.d_txg);
+        int img = img_b, ty = ty_b, txg = rem_b - ty_b * k.TXg + d_slot;
+        while (txg >= k.TXg) { txg -= k.TXg; ++ty; }
+        while (ty >= k.TYn) { ty -= k.TYn; ++img; }
+        img = img < p.NB ? img : p.NB - 1;
         // input patch: pixel (qy, par) of the slot
         {
             const int iy0 = (k.wy0 + 2 * ty + p.oy0) - p.xpad, ix = (k.wx0 + 2 * txg + p.ox0) - p.xpad + d_par;
