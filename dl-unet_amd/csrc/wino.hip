@@ -802,10 +802,10 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     issue_stage();                                    // ns >= 4
     if (wave < 2) wino_wait_vmcnt<9>(); else wino_wait_vmcnt<8>();
     __builtin_amdgcn_s_barrier();
+    read_b(0, 0);
     load_v(0);
     for (int s = 0; s < ns; ++s) {
         const int ub = s & 1;
-        read_b(ub, 0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int xg = c >> 1, h = c & 1;
@@ -820,7 +820,10 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         wino_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (s + 2 < ns) issue_stage();
-        if (s + 1 < ns) load_v((s + 1) & 1);
+        if (s + 1 < ns) {
+            read_b((s + 1) & 1, 0);           // the first B fragments of the next step fly while its V is transformed
+            load_v((s + 1) & 1);
+        }
     }
     __syncthreads();
 
@@ -950,18 +953,11 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     q.p.mtiles = cdiv(q.MT, 64);
     q.p.ntiles = p.Nn / 64;
     // variant: 0 = 512 threads x (64 tiles x 64 n), 1 = 256 threads x (64 tiles x 32 n), two per CU (UNET_WINO32: -1 auto)
-    // Measured over the net's 42 launches: the half-width variant wins whenever the K loop is short (its two
-    // independent workgroups per CU hide each other's fixed costs) or the 64-wide launch would end in a small partial
-    // round; the 64-wide one wins for >= 64 steps with a full or more than half-full last round.
-    static const int force32 = [] { const char *e = getenv("UNET_WINO32"); return e ? atoi(e) : -1; }();
-    static int ncu[64] = {0};
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (!ncu[dev]) HIP_TRY(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    const int total64 = q.p.mtiles * q.p.ntiles;
-    const int rem64 = total64 % ncu[dev];
-    const bool wide = q.nsteps >= 64 && (rem64 == 0 || 2 * rem64 >= ncu[dev]);
-    const bool half = force32 >= 0 ? force32 != 0 : !wide;
+    // Measured over the net's 42 launches: with buffer-descriptor DMA the half-width variant is the faster or
+    // equal one for every launch (19.37 vs 19.87 ms per step), so it is the default; UNET_WINO32=0 selects the 64-wide
+    // kernel (read per launch: the tests exercise both).
+    const char *e32 = getenv("UNET_WINO32");
+    const bool half = e32 ? atoi(e32) != 0 : true;
     // buffer-descriptor LDS-DMA needs every tensor below 2 GiB (32-bit num_records and the out-of-range marker)
     static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
     bool buf = usebuf != 0;

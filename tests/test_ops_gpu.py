@@ -63,7 +63,7 @@ def conv_mode(hip, request):
 
 @pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32),
                                      (3, 26, 128, 128), (1, 22, 256, 512), (2, 45, 64, 64),
-                                     (1, 66, 512, 512)])      # last: >= 64 K steps and a half-full round -> the 64-wide Winograd variant
+                                     (1, 66, 512, 512)])
 def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1); w = rnd(K, C, 3, 3, seed=2, scale=0.05); b = rnd(K, seed=3)
@@ -73,6 +73,33 @@ def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc(x))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.float().cuda())),
                                          hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc), hip.stream()), "conv3x3_fwd")
     assert nerr(nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("B,H,C,K", [(2, 45, 64, 64), (1, 66, 512, 512)])
+def test_conv3x3_wide_winograd_variant(hip, B, H, C, K, monkeypatch):
+    """The 512-thread, 64-channel-wide Winograd kernel (UNET_WINO32=0; the default is the half-width one): forward and
+    dgrad against fp64."""
+    monkeypatch.setenv("UNET_WINO32", "0")
+    default = hip.lib().unet_get_math()
+    hip.check(hip.lib().unet_set_math(3), "set_math")
+    try:
+        keep = Keep()
+        x = rnd(B, C, H, H, seed=1).requires_grad_(True); w = rnd(K, C, 3, 3, seed=2, scale=0.05).requires_grad_(True); b = rnd(K, seed=3)
+        dz = rnd(B, K, H - 2, H - 2, seed=4)
+        z = F.conv2d(x, w, b)
+        z.backward(dz)
+        y = torch.empty(B, H - 2, H - 2, K, device="cuda")
+        sc = scratch(hip.lib().unet_conv3x3_scratch_bytes(C, K))
+        hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc(x.detach()))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.detach().float().cuda())),
+                                             hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc), hip.stream()), "conv3x3_fwd")
+        assert nerr(nchw(y), F.relu(z.detach())) < TOL
+        dx = torch.empty(B, H, H, C, device="cuda")
+        sc2 = scratch(hip.lib().unet_conv3x3_bwd_scratch_bytes(B, H, H, C, K))
+        hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(keep(nhwc(x.detach()))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.detach().float().cuda())), K,
+                                             hip.ptr(keep(nhwc(dz))), hip.ptr(dx), None, None, None, None, None, None, hip.ptr(sc2), hip.stream()), "conv3x3_bwd")
+        assert nerr(nchw(dx), x.grad) < TOL
+    finally:
+        hip.check(hip.lib().unet_set_math(default), "set_math")
 
 
 @pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128),
@@ -95,7 +122,7 @@ def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
 
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True),
                                                       (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False), (2, 25, 128, 256, True, True),
-                                                      (1, 66, 512, 512, True, True)])      # last: 64-wide Winograd dgrad
+                                                      (1, 66, 512, 512, True, True)])
 def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1).requires_grad_(True)
