@@ -92,6 +92,7 @@ struct IgemmP {
     const float *mask;   // same geometry as dst: v = mask>0 ? v : 0  (ReLU backward)
     const float *add;    // same geometry as dst: v += add
     const float *zeros;
+    int buf_bytes[3];      // set by launch_igemm: buffer-descriptor sizes of src[0], src[1] and wt (bytes)
     const float *wino_u;   // math mode 3: Winograd-transformed filters of this launch (wino.hip), else null
     int mtiles, ntiles;
     FastDiv d_ohw, d_ow;   // set by launch_igemm: division by OH*OW and by OW (pixel index -> image, row, column)

@@ -40,7 +40,14 @@ void set_math_mode(int m) { g_math_mode = m; }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-template <int BM, int BN, bool PAD>
+// 16-byte LDS-DMA through a buffer descriptor (a __device__ helper: calling the builtin directly from the kernel template
+// made the host pass drop the kernel's stub without a diagnostic)
+__device__ __forceinline__ void buf_lds16(__amdgpu_buffer_rsrc_t r, unsigned char *lds, int voff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, 0, 0, 0);
+}
+
+template <int BM, int BN, bool PAD, bool BUF>
 __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
 {
     constexpr int WN = BN / 64;                 // waves along N
@@ -83,9 +90,14 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
     const float *sp = nullptr;
     int sH = 0, sW = 0, sC = 0, snch = 0, toff = 0;
 
+    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): 32-bit byte offsets, the weight column in
+    // the scalar offset, taps in the zero padding as offsets beyond num_records (the range check returns zeros).
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, BUF ? p.buf_bytes[0] : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, BUF ? p.buf_bytes[2] : 0, 0x00020000);
     auto setup_source = [&](int si) {
         const GSrc &g = p.src[si];
         sp = g.p; sH = g.H; sW = g.W; sC = g.C; snch = g.nch;
+        if (BUF) rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)g.p, 0, p.buf_bytes[si], 0x00020000);
         const int ohw = p.OH * p.OW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -105,6 +117,22 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
 
     auto stage = [&](int buf) {
         unsigned char *abase = smem + buf * STAGE + wave * (8 * 128);
+        unsigned char *bbase = abase + A_BYTES;
+        if (BUF) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                int vo = (a_off[i] + toff + kc) * 4;
+                if (PAD) {
+                    const bool inb = (unsigned)(a_iy[i] + ty) < (unsigned)sH && (unsigned)(a_ix[i] + tx) < (unsigned)sW;
+                    vo = inb ? vo : (int)0x80000000;
+                }
+                buf_lds16(rs_a, abase + i * (32 * 128), vo);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                buf_lds16(rs_b, bbase + j * (32 * 128), (b_off[j] + kglob) * 4);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const float *g = sp + (a_off[i] + toff + kc);
@@ -115,7 +143,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
             }
             GLDS16(g, abase + i * (32 * 128));
         }
-        unsigned char *bbase = abase + A_BYTES;
 #pragma unroll
         for (int j = 0; j < RB; ++j) GLDS16(p.wt + (b_off[j] + kglob), bbase + j * (32 * 128));
     };
@@ -198,12 +225,12 @@ double igemm_alg_flops(const IgemmP &p)
     return total;
 }
 
-template <int BM, int BN, bool PAD>
+template <int BM, int BN, bool PAD, bool BUF>
 static int launch_cfg(const IgemmP &p, hipStream_t st)
 {
     constexpr int LDS = 2 * (BM + BN) * 128;
     static bool attr_done[64] = {false};
-    auto kern = igemm_f32_kernel<BM, BN, PAD>;
+    auto kern = igemm_f32_kernel<BM, BN, PAD, BUF>;
     if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, attr_done)) return rc_;
     IgemmP q = p;
     q.mtiles = cdiv(p.M, BM);
@@ -258,8 +285,26 @@ int launch_igemm(IgemmP p, hipStream_t st)
     if (halo && igemmh_applicable(p)) return launch_igemmh(p, st);
     static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();
     if (gen == 2 && p.scatter != 2 && p.rw1 <= p.rw0) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
-    if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true>(p, st) : launch_cfg<128, 128, false>(p, st);
-    return pad ? launch_cfg<256, 64, true>(p, st) : launch_cfg<256, 64, false>(p, st);
+    // buffer-descriptor LDS-DMA needs sources and weights below 2 GiB
+    static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
+    bool buf = usebuf != 0;
+    for (int i = 0; i < 3; ++i) p.buf_bytes[i] = 0;
+    for (int i = 0; i < p.nsrc; ++i) {
+        const size_t b = (size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C * sizeof(float);
+        if (b >= 0x7FFFFFFFull) buf = false;
+        p.buf_bytes[i] = (int)b;
+    }
+    {
+        const size_t b = (size_t)p.Nn * p.ldw * sizeof(float);
+        if (b >= 0x7FFFFFFFull) buf = false;
+        p.buf_bytes[2] = (int)b;
+    }
+    if (buf) {
+        if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true, true>(p, st) : launch_cfg<128, 128, false, true>(p, st);
+        return pad ? launch_cfg<256, 64, true, true>(p, st) : launch_cfg<256, 64, false, true>(p, st);
+    }
+    if (p.Nn % 128 == 0) return pad ? launch_cfg<128, 128, true, false>(p, st) : launch_cfg<128, 128, false, false>(p, st);
+    return pad ? launch_cfg<256, 64, true, false>(p, st) : launch_cfg<256, 64, false, false>(p, st);
 }
 
 }  // namespace unet
