@@ -75,6 +75,15 @@ def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     assert nerr(nchw(y), ref) < TOL
 
 
+def test_conv3x3_random_shapes(hip):
+    """30 random shapes (channel counts incl. 192, batch 1-3, extents 6-64, virtual concat with pad -3..7) through the
+    forward and backward entry points in the default mode, against fp64 (tools/fuzz_conv.py)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_conv", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_conv.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    assert fz.run(30, 11, verbose=False) < TOL
+
+
 @pytest.mark.parametrize("B,H,C,K", [(2, 45, 64, 64), (1, 66, 512, 512)])
 def test_conv3x3_wide_winograd_variant(hip, B, H, C, K, monkeypatch):
     """The 512-thread, 64-channel-wide Winograd kernel (UNET_WINO32=0; the default is the half-width one): forward and
