@@ -93,6 +93,7 @@ struct IgemmP {
     const float *add;    // same geometry as dst: v += add
     const float *zeros;
     int buf_bytes[3];      // set by launch_igemm: buffer-descriptor sizes of src[0], src[1] and wt (bytes)
+    float *pool_dst;       // optional: 2x2 max-pool of the output [NB, OH/2, OW/2, Nn], written by the Winograd epilogue (wino_fuses_pool)
     const float *wino_u;   // math mode 3: Winograd-transformed filters of this launch (wino.hip), else null
     int mtiles, ntiles;
     FastDiv d_ohw, d_ow;   // set by launch_igemm: division by OH*OW and by OW (pixel index -> image, row, column)
@@ -100,6 +101,7 @@ struct IgemmP {
 int launch_igemm(IgemmP p, hipStream_t st);
 // Winograd F(2x2,3x3) path (wino.hip): filter transform into U (wino_u_floats(channels, Nn) floats) and applicability
 bool wino_applicable(const IgemmP &p);
+bool wino_fuses_pool(const IgemmP &p);
 size_t wino_u_floats(int Kc, int Nn);
 int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *U, hipStream_t st);
 int wino_transform_ref(const float *w_oihw, int I, int dgrad, int n0, int Nn, int k0, int Kc, float *U, hipStream_t st);

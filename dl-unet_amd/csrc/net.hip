@@ -461,8 +461,10 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
                                  WS(pl.wt_fwd[2 * l + 1]), PARAM(2 * (2 * l + 1) + 1), ch[l], 1, WS(pl.a2[l]));
         WLayer L2 = wl_fwd(PARAM(2 * (2 * l + 1)), ch[l], ch[l], 0, WS(pl.wt_fwd[2 * l + 1]));
         if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l + 1]), L2, 0, 0, st))) return rc;
+        const bool pool_fused = l < 4 && p.wino_u && wino_fuses_pool(p);       // the Winograd epilogue writes t[l] too
+        if (pool_fused) p.pool_dst = WS(pl.t[l]);
         if ((rc = launch_igemm(p, st))) return rc;
-        if (l < 4 && (rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
+        if (l < 4 && !pool_fused && (rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
     }
     // decoder (network.py:159-188): up-conv, virtual zero-pad-concat, two convs
     const float *dsrc = WS(pl.a2[4]);

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         unsigned char fl[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int row = (it + u) * 32 + (tid >> 3);
+            const int row = ((it >> 2) * 32 + (tid >> 3)) * 4 + u;        // the four pixels of one tile
             v[u] = *(const f32x4 *)(stg + row * 32 + 4 * c4) + bv;
             o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
             fl[u] = rflag[row];
@@ -917,6 +917,17 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (!(fl[u] & 1)) *(f32x4 *)(p.dst + o[u]) = v[u];
+        if (p.pool_dst) {
+            // fused 2x2 max-pool (network.py:132-150): a Winograd tile IS one pooling window and the linear tile index
+            // is the pooled pixel index (launch_wino checks even extents)
+            const int T = T0 + (it >> 2) * 32 + (tid >> 3);
+            if (T < k.MT) {
+                f32x4 m;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaxf(v[0][c], v[1][c]), fmaxf(v[2][c], v[3][c]));
+                *(f32x4 *)(p.pool_dst + (size_t)T * p.Nn + ncol) = m;
+            }
+        }
     }
 }
 
@@ -933,6 +944,17 @@ bool wino_applicable(const IgemmP &p)
 }
 
 size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * Nn; }
+
+// true iff launch_igemm will hand this 3x3 launch to the half-width Winograd kernel, whose epilogue can also write the 2x2
+// max-pool of its output (IgemmP::pool_dst)
+bool wino_fuses_pool(const IgemmP &p)
+{
+    if (get_math_mode() != 3 || !wino_applicable(p) || p.scatter || (p.OH & 1) || (p.OW & 1) || p.dn0 || p.DC != p.Nn) return false;
+    const char *e32 = getenv("UNET_WINO32");
+    if (e32 && atoi(e32) == 0) return false;
+    const char *ed = getenv("UNET_WINO_DBG");
+    return !(ed && atoi(ed) == 1);
+}
 
 // p must have passed launch_igemm's argument checks (launch_igemm calls this)
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
