@@ -7,23 +7,26 @@
 // All arithmetic is fp32 (v_mfma_f32_16x16x4_f32 + fp32 adds); only the evaluation order differs from the
 // direct correlation, which costs ~1e-6 relative (tests/test_ops_gpu.py pins it against the oracle).
 //
-// Work decomposition — one 512-thread workgroup (8 waves, 2 per SIMD) = 64 Winograd tiles x 64 output channels:
-//   wave (wm, wn): tiles 16*wm .. +15  x  channels 32*wn .. +31, all 16 xi  -> 16*2 accumulators of 16x16 (128 VGPRs)
+// Work decomposition — a workgroup owns 64 Winograd tiles x 32 (wino32_f32_kernel, default: 256 threads, two workgroups
+// per CU) or x 64 (wino_f32_kernel: 512 threads, one per CU) output channels; a wave owns 16 tiles x 32 channels for
+// all 16 xi -> 16*2 accumulators of 16x16 (128 VGPRs):
 //   * tiles are numbered linearly over (image, tile row, tile column): no 2-D edge waste, only the last workgroup
 //     of a launch is ragged;
-//   * per K step (8 channels) the workgroup stages by LDS-DMA  (a) every tile's private 4x4 pixel patch
-//     (64 x 16 x 32 B = 32 KiB) and (b) the U block of its 64 channels (16 x 64 x 8 x 4 B = 32 KiB, stored in
-//     global memory already in LDS/fragment order by wino_transform_kernel), double buffered, one barrier per step;
+//   * per K step (8 channels) the workgroup stages by LDS-DMA (buffer descriptors: fixed per-lane offsets, the channel
+//     step in the scalar offset, pixels outside the tensor through the range check)  (a) an 18 KiB patch image — each
+//     tile's two own pixel columns; columns 2,3 are the right neighbour's, or a per-tile-row "tail" — and (b) the
+//     16 / 32 KiB block of its channels' transformed filters U, which wino_transform_ref_kernel wrote in LDS/fragment
+//     order; 2-deep (wino32) or two 3-deep (wino) rings, one barrier per step;
 //   * the INPUT transform is done in registers: lane (tile, kg) reads its 16 pixels x 2 channels (ds_read_b64,
 //     conflict-free layout), 32 packed adds give V[xi] for those 2 channels = exactly the A operands of the 16x16x4
 //     MFMAs (k index = kg); V never exists in memory;
 //   * the OUTPUT transform is done in registers too: the accumulator layout gives a lane (channel, 4 tiles) for
-//     every xi; 24 adds per tile yield the 2x2 outputs, which go through LDS to 256-B-contiguous float4 stores with
-//     the usual fused epilogue (bias, +add, ReLU / deferred-ReLU window, ReLU' mask).
+//     every xi; 24 adds per tile yield the 2x2 outputs, which go through LDS to 128-B-contiguous float4 stores with
+//     the usual fused epilogue (bias, +add, ReLU / deferred-ReLU window, ReLU' mask) and, for the layers in front of
+//     a max-pool, the pooled tensor as well (a tile is one pooling window).
 //
-// Why this shape: accumulators are 16x the output tile, so the tile is small (64x64) and the staged bytes per MFMA
-// cycle are the limit — 64 KiB per 4096 cycles = 16 B/clk/CU through the L1/LDS-DMA path (of ~64), ~10 B/clk from
-// L2 (patch overlap hits L1); LDS reads 47 B/clk (of 256).
+// Why this shape: accumulators are 16x the output tile, so the tile is small and the staged bytes per MFMA cycle are
+// what a step has to hide: 34 KiB (wino32) per 64 MFMAs per wave.  DESIGN.md section 4 has the history and the numbers.
 #include "common.hpp"
 #include "igemm_epilogue.hpp"
 #include <cstdio>
