@@ -21,6 +21,15 @@ _SIGS = {
     "unet_abi_version": (C.c_int, []),
     "unet_set_math": (C.c_int, [C.c_int]),
     "unet_get_math": (C.c_int, []),
+    "unet_set_lds_dma": (C.c_int, [C.c_int]),
+    "unet_dp_unique_id": (C.c_int, [vp]),
+    "unet_dp_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "unet_dp_destroy": (C.c_int, [vp]),
+    "unet_dp_world": (C.c_int, [vp]),
+    "unet_dp_rccl_version": (C.c_int, []),
+    "unet_dp_allreduce": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "unet_dp_broadcast": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp]),
+    "unet_dp_join": (C.c_int, [vp, vp]),
     "unet_create": (C.c_int, [C.POINTER(vp), vp]),
     "unet_destroy": (C.c_int, [vp]),
     "unet_output_size": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
@@ -35,7 +44,8 @@ _SIGS = {
     "unet_debug_buffer": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "unet_profile_enable": (C.c_int, [C.c_int]),
     "unet_profile_reset": (C.c_int, []),
-    "unet_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "unet_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "unet_profile_dump": (C.c_int, [C.c_char_p]),
     "unet_bce_scratch_bytes": (C.c_size_t, [C.c_size_t]),
     "unet_bce_logits": (C.c_int, [vp, vp, vp, C.c_long, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
@@ -71,7 +81,7 @@ EXPORTS = tuple(_SIGS.keys())
 
 
 class UnetConfig(C.Structure):
-    _fields_ = [("base_ch", C.c_int), ("device", C.c_int)]
+    _fields_ = [("base_ch", C.c_int), ("device", C.c_int), ("math", C.c_int)]
 
 
 def build(force=False):
@@ -115,8 +125,16 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None):
+    """The current HIP stream of `device` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def run(name, device, *args):
+    """lib().<name>(*args, stream): `device` is made current for the call (everything the library keeps per device —
+    zero page, kernel attributes — is keyed on the current device) and the work goes to that device's current stream."""
+    with torch.cuda.device(device):
+        check(getattr(lib(), name)(*args, stream(device)), name)
 
 
 def ptr_table(tensors):
@@ -131,12 +149,14 @@ def ptr_table(tensors):
 class Handle:
     """RAII wrapper of unet_handle (one per device / module)."""
 
-    def __init__(self, base_ch=64, device=0):
+    def __init__(self, base_ch=64, device=0, math=-1):
+        """math: arithmetic mode of this handle (include/unet_hip.h unet_set_math codes); -1 follows unet_set_math."""
         self._h = C.c_void_p()
-        cfg = UnetConfig(base_ch, device)
+        cfg = UnetConfig(base_ch, device, math)
         check(lib().unet_create(C.byref(self._h), C.byref(cfg)), "unet_create")
         self.base_ch = base_ch
         self.device = device
+        self.math = math
 
     def __del__(self):
         try:

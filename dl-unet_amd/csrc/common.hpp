@@ -26,9 +26,16 @@ const float *zero_page();          // 4 KiB of device zeros on the current devic
         if (!(cond)) { unet::set_error(__VA_ARGS__); return -2; }                  \
     } while (0)
 
-// per-family event timing (prof.hip); family 0 = igemm, 1 = wgrad, 2 = wgrad reduce, 3 = winograd
-void prof_begin(int family, double flops, hipStream_t st, const char *tag = nullptr);
+// per-launch event timing (prof.hip).  kind: which kernel family; prof_scope names the SURVEY 8a row the following
+// launches of this thread belong to ("conv12c.fwd", "pool1.bwd", ...; nullptr clears).
+enum { PK_IGEMM = 0, PK_WGRAD = 1, PK_REDUCE = 2, PK_WINO = 3, PK_STENCIL = 4, PK_ELEMWISE = 5, PK_COMM = 6, PK_KINDS = 7 };
+void prof_scope(const char *row);
+void prof_begin(int kind, const char *tag, hipStream_t st, double alg_flops, double exec_flops, double alg_bytes);
 void prof_end(hipStream_t st);
+struct ProfScope {          // RAII: names the row for the launches of a block
+    explicit ProfScope(const char *row) { prof_scope(row); }
+    ~ProfScope() { prof_scope(nullptr); }
+};
 
 // raise a kernel's dynamic-LDS limit once per (kernel, device)
 static inline int ensure_dynamic_lds(const void *kern, int bytes, bool (&done)[64])
@@ -95,6 +102,7 @@ struct IgemmP {
     int buf_bytes[3];      // set by launch_igemm: buffer-descriptor sizes of src[0], src[1] and wt (bytes)
     float *pool_dst;       // optional: 2x2 max-pool of the output [NB, OH/2, OW/2, Nn], written by the Winograd epilogue (wino_fuses_pool)
     const float *wino_u;   // math mode 3: Winograd-transformed filters of this launch (wino.hip), else null
+    int math;              // arithmetic of this launch (unet_set_math codes); the plan fixes it at forward time
     int mtiles, ntiles;
     FastDiv d_ohw, d_ow;   // set by launch_igemm: division by OH*OW and by OW (pixel index -> image, row, column)
 };
@@ -103,10 +111,13 @@ int launch_igemm(IgemmP p, hipStream_t st);
 bool wino_applicable(const IgemmP &p);
 bool wino_fuses_pool(const IgemmP &p);
 size_t wino_u_floats(int Kc, int Nn);
-int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *U, hipStream_t st);
 int wino_transform_ref(const float *w_oihw, int I, int dgrad, int n0, int Nn, int k0, int Kc, float *U, hipStream_t st);
-int get_math_mode();
+int get_math_mode();          // process default (UNET_MATH / unet_set_math); plans and per-op calls copy it into their descriptors
 void set_math_mode(int m);
+int get_lds_dma_mode();       // 1 (default): buffer-descriptor LDS-DMA when every tensor of a launch is below 2 GiB; 0: always global_load_lds
+void set_lds_dma_mode(int m);
+double igemm_alg_flops(const IgemmP &p);
+double igemm_alg_bytes(const IgemmP &p);
 
 // ---------------------------------------------------------------------------------------------
 // Weight-gradient descriptor (wgrad.hip):  D[t][i][j] = sum_{img,y,x} X[img][(y+oy0)*s+ty-xpad][(x+ox0)*s+tx-xpad][xc0+i]
@@ -124,8 +135,11 @@ struct WgradP {
     int db_on_x;                       // 1: db[xc0 + i] = sum X instead (up-conv: X is dOut, stride == taps so every X pixel is staged once)
     float *slab; size_t slab_bytes;    // scratch for partials
     const float *zeros;
+    int math;                          // arithmetic of this launch (unet_set_math codes)
 };
-size_t wgrad_slab_need(const WgradP &p);   // slab bytes launch_wgrad will use for this descriptor
+size_t wgrad_slab_need(const WgradP &p);   // slab bytes launch_wgrad will use for this descriptor (p.math decides the kernel)
+double wgrad_alg_flops(const WgradP &p);
+double wgrad_alg_bytes(const WgradP &p);
 int launch_wgrad(WgradP p, hipStream_t st);
 
 // Packers from the reference's parameter layouts into the igemm weight matrices (direct.hip)

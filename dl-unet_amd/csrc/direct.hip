@@ -11,18 +11,22 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 
 // ============================================================================================
 // conv11c: x [B,S,S] (C=1) -> y [B,S-2,S-2,K] NHWC, + bias + ReLU.        network.py:23,131 (A1)
-// 16 lanes per pixel (float4 of channels each) when K=64: every store instruction writes 4 whole
-// pixels = 1 KiB contiguous.  The 9 taps are re-read from L1; the layer is bound by the output write.
+// The one true stencil layer: 4.4 FLOP/B, bound by the output write (83 MB per 572^2 tile).
+// A workgroup walks whole output rows: the three input rows of a row are contiguous in memory and are staged into
+// LDS once (float4 loads), the 9 taps and the bias live in registers, and CG = K/4 lanes cover a pixel's channels,
+// so every store instruction writes 4 (K=64) whole pixels = 1 KiB contiguous.  No per-pixel index arithmetic beyond
+// one add: the row decomposition is one scalar division per row.
 // ============================================================================================
 template <int K>
 __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ bias, float *__restrict__ y,
-                                                          int B, int S)
+                                                          int S, int nrows)
 {
     constexpr int CG = K / 4;                 // lanes per pixel
-    constexpr int PPB = 256 / CG;             // pixels per pass per block
+    constexpr int PPP = 256 / CG;             // pixels per pass per block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+    float *xs = (float *)smem_;               // [3][S]
     const int So = S - 2;
-    const size_t npix = (size_t)B * So * So;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
     float wr[9][4], bv[4];
 #pragma unroll
@@ -31,72 +35,98 @@ __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restric
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[t][c] = w[(cg * 4 + c) * 9 + t];
     }
-    for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
-        const int img = (int)(pix / ((size_t)So * So));
-        const int rem = (int)(pix - (size_t)img * So * So);
-        const int oy = rem / So, ox = rem - oy * So;
-        const float *xp = x + ((size_t)img * S + oy) * S + ox;
-        float xv[9];
+    const int n4 = (3 * S) >> 2;              // S % 4 == 0 (S = 16L + 60)
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int img = row / So, oy = row - img * So;
+        const float4_ *xp = (const float4_ *)(x + ((size_t)img * S + oy) * S);
+        __syncthreads();                      // the previous row's readers are done with xs
+        for (int i = threadIdx.x; i < n4; i += 256) ((float4_ *)xs)[i] = xp[i];
+        __syncthreads();
+        float *yrow = y + (size_t)row * So * K + cg * 4;
+        for (int ox = pl; ox < So; ox += PPP) {
+            float xv[9];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) xv[r * 3 + s] = xp[r * S + s];
-        float4_ o;
+                for (int q = 0; q < 3; ++q) xv[r * 3 + q] = xs[r * S + ox + q];
+            float4_ o;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float a = bv[c];
+            for (int c = 0; c < 4; ++c) {
+                float a = bv[c];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) a = fmaf(xv[t], wr[t][c], a);
-            o[c] = a > 0.f ? a : 0.f;
+                for (int t = 0; t < 9; ++t) a = fmaf(xv[t], wr[t][c], a);
+                o[c] = a > 0.f ? a : 0.f;
+            }
+            *(float4_ *)(yrow + (size_t)ox * K) = o;
         }
-        *(float4_ *)(y + pix * K + cg * 4) = o;
     }
 }
 
-// dW[k][t] = sum_p x[p+off_t] * dz[p][k],  db[k] = sum_p dz[p][k].   Partials per block, then reduce.
+// dW[k][t] = sum_p x[p+off_t] * dz[p][k],  db[k] = sum_p dz[p][k]: bound by the one read of dz.  Same row walk as the
+// forward; every lane keeps 10 x 4 partial sums in registers over all its pixels, the pixel slots of a wave are then
+// combined with wave shuffles and the four waves through 10 KiB of LDS: one partial vector per workgroup, reduced by
+// conv1ch_wgrad_reduce_kernel in a fixed order (deterministic).
 template <int K>
 __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                            float *__restrict__ partial, int B, int S)
+                                                            float *__restrict__ partial, int S, int nrows, int rows_per_block)
 {
-    constexpr int CG = K / 4, PPB = 256 / CG;
+    constexpr int CG = K / 4, PPP = 256 / CG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+    float *xs = (float *)smem_;               // [3][S], reused for the cross-wave reduction [4][10][K] (the launch sizes the LDS for both)
     const int So = S - 2;
-    const size_t npix = (size_t)B * So * So;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
     float acc[10][4];
 #pragma unroll
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
-    for (size_t pix = (size_t)blockIdx.x * PPB + pl; pix < npix; pix += (size_t)gridDim.x * PPB) {
-        const int img = (int)(pix / ((size_t)So * So));
-        const int rem = (int)(pix - (size_t)img * So * So);
-        const int oy = rem / So, ox = rem - oy * So;
-        const float *xp = x + ((size_t)img * S + oy) * S + ox;
-        const float4_ g = *(const float4_ *)(dz + pix * K + cg * 4);
+    const int n4 = (3 * S) >> 2;
+    const int row0 = blockIdx.x * rows_per_block;
+    int row1 = row0 + rows_per_block; row1 = row1 < nrows ? row1 : nrows;
+    for (int row = row0; row < row1; ++row) {
+        const int img = row / So, oy = row - img * So;
+        const float4_ *xp = (const float4_ *)(x + ((size_t)img * S + oy) * S);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n4; i += 256) ((float4_ *)xs)[i] = xp[i];
+        __syncthreads();
+        const float *zrow = dz + (size_t)row * So * K + cg * 4;
+#pragma unroll 2
+        for (int ox = pl; ox < So; ox += PPP) {
+            const float4_ g = *(const float4_ *)(zrow + (size_t)ox * K);
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const float xv = xp[r * S + s];
+                for (int q = 0; q < 3; ++q) {
+                    const float xv = xs[r * S + ox + q];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r * 3 + s][c] = fmaf(xv, g[c], acc[r * 3 + s][c]);
-            }
+                    for (int c = 0; c < 4; ++c) acc[r * 3 + q][c] = fmaf(xv, g[c], acc[r * 3 + q][c]);
+                }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[9][c] += g[c];
+            for (int c = 0; c < 4; ++c) acc[9][c] += g[c];
+        }
     }
-    // block reduction over the PPB pixel slots through LDS: red[pl][t][k]
-    __shared__ float red[PPB][10 * K / 4 + 1][4];   // (+1 pad row) indexed [pl][t*CG+cg][c]
+    // pixel slots of a wave: lanes cg, cg + CG, ... -> butterfly over the lane bits above CG
 #pragma unroll
     for (int t = 0; t < 10; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) red[pl][t * CG + cg][c] = acc[t][c];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 10 * K; e += 256) {
-        const int t = e / K, kk = e - t * K;
-        float s = 0.f;
-        for (int q = 0; q < PPB; ++q) s += red[q][t * CG + kk / 4][kk & 3];
-        partial[(size_t)blockIdx.x * 10 * K + e] = s;
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[t][c];
+#pragma unroll
+            for (int d = CG; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+            acc[t][c] = v;
+        }
+    __syncthreads();                          // xs is free
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *red = xs;                          // [4 waves][10][K]
+    if (lane < CG) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[(wave * 10 + t) * K + lane * 4 + c] = acc[t][c];
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 10 * K; e += 256)
+        partial[(size_t)blockIdx.x * 10 * K + e] = (red[e] + red[10 * K + e]) + (red[20 * K + e] + red[30 * K + e]);
 }
 
 // out: dw[k][t] (t<9) and db[k] from partial[nb][10][K]; one wave per output, lanes over the partials
@@ -325,25 +355,33 @@ static inline int grid_for(size_t total, int per_block = 256, int cap = 8192)
 
 int pack_conv_fwd(const float *w, float *wt, int K, int C1, int C2, hipStream_t st)
 {
+    prof_begin(PK_ELEMWISE, "pack_conv_fwd", st, 0.0, 0.0, 8.0 * (double)((size_t)K * (C1 + C2) * 9));
     hipLaunchKernelGGL(pack_conv_fwd_kernel, dim3(grid_for((size_t)K * (C1 + C2) * 9)), dim3(256), 0, st, w, wt, K, C1, C2);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int pack_conv_dgrad(const float *w, float *wt, int K, int C, hipStream_t st)
 {
+    prof_begin(PK_ELEMWISE, "pack_conv_dgrad", st, 0.0, 0.0, 8.0 * (double)((size_t)K * C * 9));
     hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3(grid_for((size_t)K * C * 9)), dim3(256), 0, st, w, wt, K, C);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int pack_upconv_fwd(const float *w, float *wt, int Ci, int Co, hipStream_t st)
 {
+    prof_begin(PK_ELEMWISE, "pack_upconv_fwd", st, 0.0, 0.0, 8.0 * (double)((size_t)Ci * Co * 4));
     hipLaunchKernelGGL(pack_upconv_fwd_kernel, dim3(grid_for((size_t)Ci * Co * 4)), dim3(256), 0, st, w, wt, Ci, Co);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int pack_upconv_dgrad(const float *w, float *wt, int Ci, int Co, hipStream_t st)
 {
+    prof_begin(PK_ELEMWISE, "pack_upconv_dgrad", st, 0.0, 0.0, 8.0 * (double)((size_t)Ci * Co * 4));
     hipLaunchKernelGGL(pack_upconv_dgrad_kernel, dim3(grid_for((size_t)Ci * Co * 4)), dim3(256), 0, st, w, wt, Ci, Co);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -395,8 +433,10 @@ int bias_grad(const float *dz, size_t M, int K, float *db, float *scratch, hipSt
 {
     ARG_CHECK(K % 4 == 0 && K / 4 <= 256, "bias_grad: K=%d unsupported", K);
     const int nb = (int)((M + BG_ROWS - 1) / BG_ROWS);
+    prof_begin(PK_ELEMWISE, "bias_grad", st, (double)M * K, 0.0, 4.0 * (double)M * K);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(256), 0, st, dz, M, K, scratch);
     hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, scratch, nb, K, db);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -483,25 +523,53 @@ __global__ void argmax2_kernel(const float *__restrict__ x, long bs, long ps, lo
     }
 }
 
+// L3: buf = first ? g : mu*buf + g ; p -= lr*buf over <= 46 tensors in one launch.  HBM-bound (3 reads + 2 writes per
+// element): a workgroup takes 4096-element chunks of one tensor (16 B per lane per access; the tensors' tails and any
+// tensor whose pointers are not 16-byte aligned take 4-byte accesses).  The multiply and the add are rounded separately,
+// like the reference's buf.mul_(mu).add_(g); p.add_(buf, alpha=-lr).
+constexpr int SGD_CHUNK = 4096;
 struct SgdTable { float *p[UNET_N_PARAMS]; const float *g[UNET_N_PARAMS]; float *b[UNET_N_PARAMS];
-                  unsigned long long start[UNET_N_PARAMS + 1]; int n; };
+                  unsigned long long numel[UNET_N_PARAMS]; unsigned cstart[UNET_N_PARAMS + 1]; int n; };
+template <bool VEC>
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(const SgdTable tb, float lr, float mu, int first)
 {
-    // each block handles 4096 consecutive elements of the virtual concatenation of all tensors
-    const unsigned long long total = tb.start[tb.n];
-    for (unsigned long long base = (unsigned long long)blockIdx.x * 4096; base < total; base += (unsigned long long)gridDim.x * 4096) {
+    const unsigned nchunks = tb.cstart[tb.n];
+    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         int t = 0;
-        while (t + 1 < tb.n && tb.start[t + 1] <= base) ++t;
-        for (int i = threadIdx.x; i < 4096; i += 256) {
-            unsigned long long e = base + i;
-            if (e >= total) break;
-            while (tb.start[t + 1] <= e) ++t;
-            const unsigned long long o = e - tb.start[t];
-            const float g = tb.g[t][o];
-            // separately rounded multiply and add, like the reference's buf.mul_(mu).add_(g); p.add_(buf, alpha=-lr)
-            const float b = first ? g : __fadd_rn(__fmul_rn(mu, tb.b[t][o]), g);
-            tb.b[t][o] = b;
-            tb.p[t][o] = __fsub_rn(tb.p[t][o], __fmul_rn(lr, b));
+        while (tb.cstart[t + 1] <= chunk) ++t;                      // scalar: chunk is uniform
+        const unsigned long long n = tb.numel[t];
+        const unsigned long long off = (unsigned long long)(chunk - tb.cstart[t]) * SGD_CHUNK;
+        float *pp = tb.p[t] + off; const float *gp = tb.g[t] + off; float *bp = tb.b[t] + off;
+        const unsigned long long left = n - off;
+        if (VEC && left >= SGD_CHUNK) {
+            float4_ g[4], b[4], q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = ((const float4_ *)gp)[i * 256 + threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = ((const float4_ *)pp)[i * 256 + threadIdx.x];
+            if (!first) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = ((const float4_ *)bp)[i * 256 + threadIdx.x];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float bn = first ? g[i][c] : __fadd_rn(__fmul_rn(mu, b[i][c]), g[i][c]);
+                    b[i][c] = bn;
+                    q[i][c] = __fsub_rn(q[i][c], __fmul_rn(lr, bn));
+                }
+                ((float4_ *)bp)[i * 256 + threadIdx.x] = b[i];
+                ((float4_ *)pp)[i * 256 + threadIdx.x] = q[i];
+            }
+        } else {
+            const int m = left < SGD_CHUNK ? (int)left : SGD_CHUNK;
+            for (int i = threadIdx.x; i < m; i += 256) {
+                const float g = gp[i];
+                const float bn = first ? g : __fadd_rn(__fmul_rn(mu, bp[i]), g);
+                bp[i] = bn;
+                pp[i] = __fsub_rn(pp[i], __fmul_rn(lr, bn));
+            }
         }
     }
 }
@@ -515,25 +583,42 @@ extern "C" {
 int unet_conv1ch_fwd(const void *x, int B, int S, const void *w, const void *bias, int K, void *y, void *stream)
 {
     ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
-    const size_t npix = (size_t)B * (S - 2) * (S - 2);
-    const int ppb = 256 / (K / 4);
-    const int grid = grid_for(npix, ppb * 8, 16384);
-    if (K == 64) hipLaunchKernelGGL(conv1ch_fwd_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)y, B, S);
-    else hipLaunchKernelGGL(conv1ch_fwd_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)y, B, S);
+    ARG_CHECK(S >= 3 && S % 4 == 0, "conv1ch: S=%d must be a multiple of 4", S);
+    hipStream_t st = (hipStream_t)stream;
+    const int So = S - 2, nrows = B * So;
+    const int grid = nrows < 2048 ? nrows : 2048;
+    const size_t lds = (size_t)3 * S * sizeof(float);
+    prof_begin(PK_STENCIL, "conv1ch_fwd", st, 18.0 * nrows * So * K, 0.0, 4.0 * ((double)B * S * S + (double)nrows * So * K));
+    if (K == 64) hipLaunchKernelGGL(conv1ch_fwd_kernel<64>, dim3(grid), dim3(256), lds, st, (const float *)x, (const float *)w, (const float *)bias, (float *)y, S, nrows);
+    else hipLaunchKernelGGL(conv1ch_fwd_kernel<32>, dim3(grid), dim3(256), lds, st, (const float *)x, (const float *)w, (const float *)bias, (float *)y, S, nrows);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-static int conv1ch_bwd_blocks(int B, int S) { const size_t npix = (size_t)B * (S - 2) * (S - 2); return grid_for(npix, 16 * 64, 512); }
-size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K) { return (size_t)conv1ch_bwd_blocks(B, S) * 10 * K * sizeof(float); }
+// rows per workgroup and workgroup count of the weight-gradient pass (<= 1024 partial vectors)
+static void conv1ch_bwd_split(int B, int S, int &rpb, int &nb)
+{
+    const int nrows = B * (S - 2);
+    rpb = cdiv(nrows, 1024);
+    nb = cdiv(nrows, rpb);
+}
+size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K) { int rpb, nb; conv1ch_bwd_split(B, S, rpb, nb); return (size_t)nb * 10 * K * sizeof(float); }
 int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *dw, void *db, void *scratch, void *stream)
 {
     ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
-    const int nb = conv1ch_bwd_blocks(B, S);
+    ARG_CHECK(S >= 3 && S % 4 == 0, "conv1ch: S=%d must be a multiple of 4", S);
+    int rpb, nb;
+    conv1ch_bwd_split(B, S, rpb, nb);
     hipStream_t st = (hipStream_t)stream;
-    if (K == 64) hipLaunchKernelGGL(conv1ch_wgrad_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)dz, (float *)scratch, B, S);
-    else hipLaunchKernelGGL(conv1ch_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)dz, (float *)scratch, B, S);
+    const int So = S - 2, nrows = B * So;
+    size_t lds = (size_t)3 * S * sizeof(float);
+    if (lds < (size_t)40 * K * sizeof(float)) lds = (size_t)40 * K * sizeof(float);
+    prof_begin(PK_STENCIL, "conv1ch_wgrad", st, 20.0 * nrows * So * K, 0.0, 4.0 * ((double)B * S * S + (double)nrows * So * K));
+    if (K == 64) hipLaunchKernelGGL(conv1ch_wgrad_kernel<64>, dim3(nb), dim3(256), lds, st, (const float *)x, (const float *)dz, (float *)scratch, S, nrows, rpb);
+    else hipLaunchKernelGGL(conv1ch_wgrad_kernel<32>, dim3(nb), dim3(256), lds, st, (const float *)x, (const float *)dz, (float *)scratch, S, nrows, rpb);
     hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(cdiv(10 * K, 4)), dim3(256), 0, st, (const float *)scratch, nb, K, (float *)dw, (float *)db);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -541,11 +626,14 @@ int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *d
 int unet_head1x1_fwd(const void *x, int B, int H, int W, int C, const void *w, const void *bias, void *logits, void *stream)
 {
     ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
+    hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)B * H * W;
     const int ppb = (256 / (C / 4)) * 16;
     const int grid = (int)((npix + ppb - 1) / ppb);
-    if (C == 64) hipLaunchKernelGGL(head1x1_fwd_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
-    else hipLaunchKernelGGL(head1x1_fwd_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
+    prof_begin(PK_ELEMWISE, "head1x1_fwd", st, 4.0 * npix * C, 0.0, 4.0 * npix * (C + 2));
+    if (C == 64) hipLaunchKernelGGL(head1x1_fwd_kernel<64>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
+    else hipLaunchKernelGGL(head1x1_fwd_kernel<32>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -558,9 +646,12 @@ int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, c
     ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
     const int nb = head_bwd_blocks(B, H, W);
     hipStream_t st = (hipStream_t)stream;
+    const double npix = (double)B * H * W;
+    prof_begin(PK_ELEMWISE, "head1x1_bwd", st, 8.0 * npix * C, 0.0, 4.0 * npix * (2 * C + 2));
     if (C == 64) hipLaunchKernelGGL(head1x1_bwd_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
     else hipLaunchKernelGGL(head1x1_bwd_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
     hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 4)), dim3(256), 0, st, (const float *)scratch, nb, C, (float *)dw, (float *)db);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -568,16 +659,22 @@ int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, c
 int unet_maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, void *stream)
 {
     ARG_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: H,W must be even and C a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (const float *)x, (float *)y, B, H, W, C / 4);
+    prof_begin(PK_ELEMWISE, "maxpool2_fwd", st, 0.0, 0.0, 16.0 * (double)total * 5.0);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const float *)x, (float *)y, B, H, W, C / 4);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int unet_maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, void *stream)
 {
     ARG_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: H,W must be even and C a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, (hipStream_t)stream, (const float *)pre, (const float *)dy, (float *)dpre, B, H, W, C / 4);
+    prof_begin(PK_ELEMWISE, "maxpool2_bwd", st, 0.0, 0.0, 16.0 * (double)total * 9.0);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const float *)pre, (const float *)dy, (float *)dpre, B, H, W, C / 4);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -590,21 +687,32 @@ int unet_bce_logits(const void *logits, const void *target, const void *weight, 
     ARG_CHECK(n > 0 && loss_out && scratch, "bce: bad arguments");
     const int nb = (int)((n + BCE_PER_BLOCK - 1) / BCE_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("L1.bce");
+    prof_begin(PK_ELEMWISE, "bce_logits", st, 0.0, 0.0, 4.0 * (double)n * (2 + (weight ? 1 : 0) + (dlogits ? 1 : 0)));
     hipLaunchKernelGGL(bce_logits_kernel, dim3(nb), dim3(256), 0, st, (const float *)logits, (const float *)target, (const float *)weight,
                        wsB, wsC, wsH, wsW, H, W, n, (float *)dlogits, grad_scale, (double *)scratch);
     hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, (const double *)scratch, nb, n, (float *)loss_out);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int unet_onehot2(const void *labels_i64, void *target, int B, int H, int W, void *stream)
 {
-    hipLaunchKernelGGL(onehot2_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, (const long long *)labels_i64, (float *)target, B, (size_t)H * W);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("L1.onehot");
+    prof_begin(PK_ELEMWISE, "onehot2", st, 0.0, 0.0, 16.0 * (double)B * H * W);
+    hipLaunchKernelGGL(onehot2_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, (const long long *)labels_i64, (float *)target, B, (size_t)H * W);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int unet_argmax2(const void *logits, long batch_stride, long plane_stride, long row_stride, void *out_i64, int B, int H, int W, void *stream)
 {
-    hipLaunchKernelGGL(argmax2_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, (const float *)logits, batch_stride, plane_stride, row_stride, (long long *)out_i64, B, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("L2.argmax");
+    prof_begin(PK_ELEMWISE, "argmax2", st, 0.0, 0.0, 16.0 * (double)B * H * W);
+    hipLaunchKernelGGL(argmax2_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, (const float *)logits, batch_stride, plane_stride, row_stride, (long long *)out_i64, B, H, W);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -614,13 +722,26 @@ int unet_sgd_momentum(void *const *params, const void *const *grads, void *const
     ARG_CHECK(n > 0 && n <= UNET_N_PARAMS, "sgd: n=%d out of range (1..%d)", n, UNET_N_PARAMS);
     SgdTable tb;
     tb.n = n;
-    unsigned long long off = 0;
+    unsigned chunks = 0;
+    unsigned long long total = 0;
+    bool vec = true;
     for (int i = 0; i < n; ++i) {
         tb.p[i] = (float *)params[i]; tb.g[i] = (const float *)grads[i]; tb.b[i] = (float *)bufs[i];
-        tb.start[i] = off; off += numel[i];
+        if (((uintptr_t)params[i] | (uintptr_t)grads[i] | (uintptr_t)bufs[i]) & 15) vec = false;
+        tb.numel[i] = numel[i];
+        tb.cstart[i] = chunks;
+        chunks += (unsigned)((numel[i] + SGD_CHUNK - 1) / SGD_CHUNK);
+        total += numel[i];
     }
-    tb.start[n] = off;
-    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(off, 4096, 8192)), dim3(256), 0, (hipStream_t)stream, tb, lr, mu, first_step);
+    tb.cstart[n] = chunks;
+    if (chunks == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = chunks < 16384u ? (int)chunks : 16384;
+    ProfScope ps("L3.sgd");
+    prof_begin(PK_ELEMWISE, "sgd_momentum", st, 4.0 * (double)total, 0.0, 4.0 * (double)total * (first_step ? 4 : 5));
+    if (vec) hipLaunchKernelGGL(sgd_momentum_kernel<true>, dim3(grid), dim3(256), 0, st, tb, lr, mu, first_step);
+    else hipLaunchKernelGGL(sgd_momentum_kernel<false>, dim3(grid), dim3(256), 0, st, tb, lr, mu, first_step);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }

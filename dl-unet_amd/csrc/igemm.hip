@@ -23,10 +23,7 @@
 
 namespace unet {
 
-int launch_igemm2(const IgemmP &p, bool pad, hipStream_t st);
 int launch_igemmx(const IgemmP &p, bool pad, int nsplit, hipStream_t st);
-int launch_igemmh(const IgemmP &p, hipStream_t st);
-bool igemmh_applicable(const IgemmP &p);
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st);
 
 // 0 = fp32 MFMA, direct (every product of the correlation: an exact fmaf chain), 1 = bf16x3 split (fp32-class accuracy on
@@ -35,6 +32,9 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st);
 static int g_math_mode = [] { const char *e = getenv("UNET_MATH"); return e ? atoi(e) : 3; }();
 int get_math_mode() { return g_math_mode; }
 void set_math_mode(int m) { g_math_mode = m; }
+static int g_lds_dma = [] { const char *e = getenv("UNET_LDS_DMA"); return e ? atoi(e) : 1; }();
+int get_lds_dma_mode() { return g_lds_dma; }
+void set_lds_dma_mode(int m) { g_lds_dma = m; }
 
 #define GLDS16(gptr, lptr)                                                                    \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),  \
@@ -225,6 +225,27 @@ double igemm_alg_flops(const IgemmP &p)
     return total;
 }
 
+// Algorithmic HBM bytes of one launch: the source pixels its taps can reach, once; the output, once (plus
+// what the fused epilogue reads: add / mask); the filter matrix, once.
+double igemm_alg_bytes(const IgemmP &p)
+{
+    double b = 0.0;
+    const int TYn = p.T / p.TX;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const GSrc &g = p.src[s];
+        int y0 = p.oy0 * p.stride - g.pad, y1 = (p.OH - 1 + p.oy0) * p.stride - g.pad + TYn;
+        int x0 = p.ox0 * p.stride - g.pad, x1 = (p.OW - 1 + p.ox0) * p.stride - g.pad + p.TX;
+        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+        y1 = y1 > g.H ? g.H : y1; x1 = x1 > g.W ? g.W : x1;
+        if (y1 > y0 && x1 > x0) b += (double)p.NB * (y1 - y0) * (x1 - x0) * g.nch * 4.0;
+    }
+    const double out = (double)p.M * p.Nn * 4.0;
+    b += out * (1.0 + (p.add ? 1.0 : 0.0) + (p.mask ? 1.0 : 0.0));
+    if (p.pool_dst) b += out / 4.0;
+    b += (double)p.Nn * p.Kd * 4.0;
+    return b;
+}
+
 template <int BM, int BN, bool PAD, bool BUF>
 static int launch_cfg(const IgemmP &p, hipStream_t st)
 {
@@ -237,7 +258,7 @@ static int launch_cfg(const IgemmP &p, hipStream_t st)
     q.ntiles = cdiv(p.Nn, BN);
     char tag[96];
     snprintf(tag, sizeof(tag), "igemm<%d;%d;%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
-    prof_begin(0, igemm_alg_flops(p), st, tag);
+    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * q.mtiles * BM * (double)q.ntiles * BN * p.Kd, igemm_alg_bytes(p));
     hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());
@@ -274,20 +295,16 @@ int launch_igemm(IgemmP p, hipStream_t st)
     if (!p.zeros) return -2;
     p.d_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
     p.d_ow = make_fastdiv((unsigned)p.OW);
-    if (g_math_mode == 3 && p.wino_u && wino_applicable(p)) {
+    ARG_CHECK(p.math >= 0 && p.math <= 3, "igemm: bad arithmetic mode %d", p.math);
+    if (p.math == 3 && p.wino_u && wino_applicable(p)) {
         ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemm: destination exceeds 31-bit element offsets");
         return launch_wino(p, p.wino_u, st);
     }
-    if (g_math_mode == 1) return launch_igemmx(p, pad, 3, st);
-    if (g_math_mode == 2) return launch_igemmx(p, pad, 1, st);
-    static const int halo = [] { const char *e = getenv("UNET_HALO"); return e ? atoi(e) : 0; }();   // opt-in: measured 0-15 % slower in fp32
+    if (p.math == 1) return launch_igemmx(p, pad, 3, st);
+    if (p.math == 2) return launch_igemmx(p, pad, 1, st);
     ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemm: destination exceeds 31-bit element offsets");
-    if (halo && igemmh_applicable(p)) return launch_igemmh(p, st);
-    static const int gen = [] { const char *e = getenv("UNET_IGEMM"); return e ? atoi(e) : 1; }();
-    if (gen == 2 && p.scatter != 2 && p.rw1 <= p.rw0) return launch_igemm2(p, pad, st);      // experimental K-step-16 / 3-stage variant (igemm2.hip)
     // buffer-descriptor LDS-DMA needs sources and weights below 2 GiB
-    static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
-    bool buf = usebuf != 0;
+    bool buf = g_lds_dma != 0;
     for (int i = 0; i < 3; ++i) p.buf_bytes[i] = 0;
     for (int i = 0; i < p.nsrc; ++i) {
         const size_t b = (size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C * sizeof(float);

@@ -1,4 +1,4 @@
-// igemm_epilogue.hpp — epilogue shared by the implicit-GEMM kernels (igemm.hip, igemm3.hip).
+// igemm_epilogue.hpp — epilogue shared by the implicit-GEMM kernels (igemm.hip, igemmx.hip).
 #pragma once
 #include "common.hpp"
 
@@ -115,82 +115,6 @@ __device__ __forceinline__ void igemm_epilogue_store(const IgemmP &p, f32x16 (&a
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (n_ok && m0 + wm * 64 + tm * 32 + rrow + 8 * k < p.M) *(f32x4 *)(p.dst + o[k]) = v[k];
-        }
-    }
-}
-
-// same, for 2-D tiles (igemmh.hip): validity of a row is bit 31 of its table entry instead of m0 + row < M
-template <int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue_store_flagged(const IgemmP &p, f32x16 (&acc)[2][2], int n0, int tid,
-                                                     unsigned char *lds /* >= BM*5 + 4*EPI_WAVE_BYTES bytes */)
-{
-    constexpr int WN = BN / 64;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, lh = lane >> 5;
-    unsigned *rowoff = (unsigned *)lds;
-    float *patch = (float *)(lds + BM * 4 + wave * EPI_WAVE_BYTES);
-    unsigned char *inwin = lds + BM * 4 + 4 * EPI_WAVE_BYTES;
-    const bool relu_win = p.rw1 > p.rw0;
-    const int rrow = lane >> 3, cg = lane & 7;           // read-back role: row rrow + 8k, columns 4cg..4cg+3
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int nb = n0 + wn * 64 + tn * 32;
-        float bv = 0.f;
-        if (p.bias) {
-            int n = nb + l31;
-            n = n < p.Nn ? n : p.Nn - 1;
-            bv = p.bias[p.cout ? n % p.cout : n];
-        }
-        const int n4 = nb + 4 * cg;
-        const bool n_ok = n4 < p.Nn;
-        const int nc = n_ok ? n4 : 0;
-        int coloff;
-        if (p.scatter != 1) {
-            coloff = p.dn0 + nc;
-        } else {
-            const int ab = nc / p.cout;
-            coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + (nc - ab * p.cout);
-        }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_PITCH + l31] = acc[tm][tn][r] + bv;
-            f32x4 v[4];
-            size_t o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = *(const f32x4 *)(patch + (rrow + 8 * k) * EPI_PITCH + 4 * cg);
-                o[k] = (size_t)(rowoff[wm * 64 + tm * 32 + rrow + 8 * k] & 0x7FFFFFFFu) + (size_t)coloff;
-            }
-            if (p.add) {
-                f32x4 t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = *(const f32x4 *)(p.add + o[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += t[k];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool defer = relu_win && inwin[wm * 64 + tm * 32 + rrow + 8 * k];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[k][c] = (v[k][c] > 0.f || defer) ? v[k][c] : 0.f;
-                }
-            }
-            if (p.mask) {
-                f32x4 t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = *(const f32x4 *)(p.mask + o[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[k][c] = t[k][c] > 0.f ? v[k][c] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (n_ok && !(rowoff[wm * 64 + tm * 32 + rrow + 8 * k] & 0x80000000u)) *(f32x4 *)(p.dst + o[k]) = v[k];
         }
     }
 }

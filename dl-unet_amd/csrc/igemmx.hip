@@ -199,8 +199,6 @@ __global__ __launch_bounds__(256, 2) void igemmx_kernel(const IgemmP p)
     igemm_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
 }
 
-double igemm_alg_flops(const IgemmP &p);
-
 template <int BM, int BN, bool PAD, int NSPLIT>
 static int launch_cfgx(const IgemmP &p, hipStream_t st)
 {
@@ -213,7 +211,7 @@ static int launch_cfgx(const IgemmP &p, hipStream_t st)
     q.ntiles = cdiv(p.Nn, BN);
     char tag[96];
     snprintf(tag, sizeof(tag), "igemmx<%d;%d;%d;split%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, NSPLIT, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
-    prof_begin(0, igemm_alg_flops(p), st, tag);
+    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * NSPLIT * q.mtiles * BM * (double)q.ntiles * BN * p.Kd, igemm_alg_bytes(p));
     hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());

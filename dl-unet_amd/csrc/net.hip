@@ -50,6 +50,7 @@ static const int C2E_L[4] = {C12E, C22E, C32E, C42E};
 
 struct Plan {
     int B = 0, S = 0, base = 0, So = 0, training = 0;
+    int math = 3;         // arithmetic, fixed when the forward is planned: the backward of that forward uses the same
     int ch[5];
     int ein[5], ea1[5], ea2[5], et[4], eu[4], ed1[4], ed2[4], pad[4];
     size_t a1[5], a2[5], t[4], u[4], d1[4], d2[4];
@@ -64,12 +65,14 @@ struct Plan {
 
 using namespace unet;
 
+struct unet_dp;       // dp.hip: RCCL communicator + its stream (null until unet_dp_init)
+int unet_dp_free(unet_dp *d);
+
 struct unet_handle {
     int base_ch;
     int device;
-    // backward: the weight gradients run on an auxiliary stream next to the dgrad chain (they only share dz)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int math;             // arithmetic of this handle's forwards (unet_config::math); -1 = the process default at each forward
+    unet_dp *dp = nullptr;
     // plans of the training forwards still awaiting their backward, keyed by workspace pointer
     std::mutex mu;
     std::vector<std::pair<void *, Plan>> live;
@@ -87,6 +90,9 @@ struct unet_handle {
         return false;
     }
 };
+
+unet_dp **unet_handle_dp_slot(unet_handle *h) { return &h->dp; }
+int unet_handle_device(const unet_handle *h) { return h->device; }
 
 namespace unet {
 
@@ -152,7 +158,7 @@ static WLayer wl_dgrad(const float *w, int K, int C, float *wt) { return WLayer{
 // launch's filter matrix within the layer) into `wu`; otherwise make sure the packed igemm weights exist.
 static int with_wino(IgemmP &p, float *wu, WLayer &L, int n0, int k0, hipStream_t st)
 {
-    if (get_math_mode() != 3 || !wu || !wino_applicable(p)) return L.ensure_packed(st);
+    if (p.math != 3 || !wu || !wino_applicable(p)) return L.ensure_packed(st);
     int kc = 0;
     for (int i = 0; i < p.nsrc; ++i) kc += p.src[i].nch;
     int rc = wino_transform_ref(L.w, L.I, L.dgrad ? 1 : 0, n0, p.Nn, k0, kc, wu, st);
@@ -171,6 +177,26 @@ static int check_size(int S)
     return 0;
 }
 
+// Arithmetic mode of the C-ABI call this thread is in; the descriptor builders copy it into every launch descriptor
+// (handle entry points: the plan's mode; per-op entry points: the process default).
+static thread_local int t_math = 3;
+struct MathScope {
+    int prev;
+    explicit MathScope(int m) : prev(t_math) { t_math = m; }
+    ~MathScope() { t_math = prev; }
+};
+
+static const char *const LAYER_NAME[UNET_N_LAYERS] = {
+    "conv11c", "conv12c", "conv21c", "conv22c", "conv31c", "conv32c", "conv41c", "conv42c", "conv51c", "conv52c",
+    "upconv4", "conv41e", "conv42e", "upconv3", "conv31e", "conv32e", "upconv2", "conv21e", "conv22e",
+    "upconv1", "conv11e", "conv12e", "finalconv"};
+// profile row of a launch group: "<layer>.<fwd|dgrad|wgrad>" (bench.py maps them onto SURVEY 8a rows)
+struct RowScope : ProfScope {
+    static const char *make(char (&buf)[40], int layer, const char *what) { snprintf(buf, sizeof(buf), "%s.%s", LAYER_NAME[layer], what); return buf; }
+    char buf[40];
+    RowScope(int layer, const char *what) : ProfScope(make(buf, layer, what)) {}
+};
+
 // ---- descriptor builders (shared by the plan sizing and the launches) ----------------------------
 static IgemmP conv_fwd_desc(const float *x1, int H1, int W1, int C1, int pad1, const float *x2, int C2,
                             int B, int H, int W, const float *wt, const float *bias, int K, int relu, float *y)
@@ -184,6 +210,7 @@ static IgemmP conv_fwd_desc(const float *x1, int H1, int W1, int C1, int pad1, c
     p.NB = B; p.OH = H - 2; p.OW = W - 2; p.M = B * p.OH * p.OW; p.Nn = K;
     p.dst = y; p.DH = p.OH; p.DW = p.OW; p.DC = K; p.dn0 = 0;
     p.bias = bias; p.relu = relu;
+    p.math = t_math;
     return p;
 }
 
@@ -234,6 +261,7 @@ static IgemmP conv_dgrad_desc(const float *dz, int Ho, int Wo, int K, int B, int
     p.NB = B; p.OH = OHW; p.OW = OHW; p.M = B * OHW * OHW; p.Nn = Nn;
     p.dst = dx; p.DH = OHW; p.DW = OHW; p.DC = Nn; p.dn0 = 0;
     p.mask = mask; p.add = add;
+    p.math = t_math;
     return p;
 }
 
@@ -250,6 +278,7 @@ static WgradP conv_wgrad_desc(const float *X, int XH, int XC, int xpad, const fl
     p.Ci = XC; p.Cj = K;
     p.out = dw ? dw + (size_t)c_off * 9 : nullptr; p.si = 9; p.sj = (long)Ctot * 9; p.st = 1;
     p.slab = slab; p.slab_bytes = slab_bytes; p.db = db;
+    p.math = t_math;
     return p;
 }
 
@@ -265,16 +294,18 @@ static WgradP upconv_wgrad_desc(const float *x, int H, int Ci, const float *dy, 
     p.out = dw; p.si = 4; p.sj = (long)Co * 4; p.st = 1;
     p.slab = slab; p.slab_bytes = slab_bytes;
     p.db = db; p.db_on_x = db ? 1 : 0;        // db[co] = sum dOut: X is dOut here
+    p.math = t_math;
     return p;
 }
 
-static int make_plan(Plan &pl, int base, int B, int S, int training)
+static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
 {
     int rc = check_size(S);
     if (rc) return rc;
     if (B <= 0) { set_error("batch must be positive"); return UNET_E_BADARG; }
     pl = Plan();
-    pl.B = B; pl.S = S; pl.base = base; pl.training = training;
+    pl.B = B; pl.S = S; pl.base = base; pl.training = training; pl.math = math;
+    MathScope ms(math);                      // the slab sizing below builds weight-gradient descriptors
     for (int l = 0; l < 5; ++l) pl.ch[l] = base << l;
     int cur = S;
     for (int l = 0; l < 5; ++l) {
@@ -347,7 +378,7 @@ static int make_plan(Plan &pl, int base, int B, int S, int training)
 extern "C" {
 
 const char *unet_last_error(void) { return g_err; }
-int unet_abi_version(void) { return 1; }
+int unet_abi_version(void) { return 2; }
 
 int unet_set_math(int mode)
 {
@@ -357,29 +388,51 @@ int unet_set_math(int mode)
 }
 int unet_get_math(void) { return get_math_mode(); }
 
+int unet_set_lds_dma(int mode)
+{
+    ARG_CHECK(mode == 0 || mode == 1, "unet_set_lds_dma: mode must be 0 (global_load_lds) or 1 (buffer descriptors when tensors fit)");
+    set_lds_dma_mode(mode);
+    return 0;
+}
+
+// the device a call must run on: the handle's.  Everything the library keeps per device (zero page, LDS attributes) is
+// keyed on hipGetDevice(), so a call made while another device is current would enqueue on the wrong device.
+#define CHECK_DEVICE(h, what)                                                                                          \
+    do {                                                                                                               \
+        int cur_ = -1;                                                                                                 \
+        HIP_TRY(hipGetDevice(&cur_));                                                                                  \
+        ARG_CHECK(cur_ == (h)->device, what ": the handle belongs to device %d but device %d is current "               \
+                  "(one process per GPU: hipSetDevice / torch.cuda.set_device first)", (h)->device, cur_);             \
+    } while (0)
+
 int unet_create(unet_handle **out, const unet_config *cfg)
 {
     ARG_CHECK(out && cfg, "unet_create: null argument");
     ARG_CHECK(cfg->base_ch == 64 || cfg->base_ch == 32, "unet_create: base_ch %d unsupported (32 or 64)", cfg->base_ch);
+    ARG_CHECK(cfg->math >= -1 && cfg->math <= 3, "unet_create: math %d unsupported (-1 = process default, 0..3)", cfg->math);
+    // the zero page is made on the handle's device; the caller's current device is left as it was
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
     HIP_TRY(hipSetDevice(cfg->device));
-    if (!zero_page()) return UNET_E_BADARG;
+    const bool ok = zero_page() != nullptr;
+    HIP_TRY(hipSetDevice(prev));
+    if (!ok) return UNET_E_BADARG;
     unet_handle *h = new unet_handle();
     h->base_ch = cfg->base_ch;
     h->device = cfg->device;
+    h->math = cfg->math;
     *out = h;
     return 0;
 }
 
 int unet_destroy(unet_handle *h)
 {
-    if (h) {
-        if (h->aux) (void)hipStreamDestroy(h->aux);
-        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    }
+    if (h && h->dp) (void)unet_dp_free(h->dp);
     delete h;
     return 0;
 }
+
+static int handle_math(const unet_handle *h) { return h->math >= 0 ? h->math : get_math_mode(); }
 
 int unet_output_size(int S, int *out_size)
 {
@@ -400,7 +453,7 @@ size_t unet_workspace_bytes(const unet_handle *h, int B, int S, int training)
 {
     if (!h) { set_error("null handle"); return 0; }
     Plan pl;
-    if (make_plan(pl, h->base_ch, B, S, training)) return 0;
+    if (make_plan(pl, h->base_ch, B, S, training, handle_math(h))) return 0;
     return pl.total;
 }
 
@@ -408,7 +461,7 @@ double unet_flops(const unet_handle *h, int B, int S, int backward)
 {
     if (!h) return 0.0;
     Plan pl;
-    if (make_plan(pl, h->base_ch, B, S, 0)) return 0.0;
+    if (make_plan(pl, h->base_ch, B, S, 0, handle_math(h))) return 0.0;
     double f = 0.0, f11c = 0.0;
     auto conv = [&](int eo, int ci, int co, int k) { return 2.0 * B * (double)eo * eo * ci * co * k * k; };
     for (int l = 0; l < 5; ++l) {
@@ -432,9 +485,11 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
                  void *workspace, size_t workspace_bytes, int training, void *stream)
 {
     ARG_CHECK(h && params && x && logits && workspace, "unet_forward: null argument");
+    CHECK_DEVICE(h, "unet_forward");
     Plan pl;
-    int rc = make_plan(pl, h->base_ch, B, S, training);
+    int rc = make_plan(pl, h->base_ch, B, S, training, handle_math(h));
     if (rc) return rc;
+    MathScope ms(pl.math);
     ARG_CHECK(workspace_bytes >= pl.total, "unet_forward: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
     ARG_CHECK(((uintptr_t)workspace & 255) == 0, "unet_forward: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -443,52 +498,78 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
     // repack the parameters (reference layout, owned by the caller and updated by its optimizer)
     // (the 3x3 layers' weights are packed lazily, only if a launch of the layer takes the implicit-GEMM path: with_wino)
     for (int l = 0; l < 4; ++l) {
+        RowScope rs(UP_L[l], "fwd");
         if ((rc = pack_upconv_fwd(PARAM(2 * UP_L[l]), WS(pl.wt_fwd[UP_L[l]]), ch[l + 1], ch[l], st))) return rc;
     }
 
     // encoder (network.py:131-156); the input is kept for conv11c's weight gradient
-    if (training) HIP_TRY(hipMemcpyAsync(WS(pl.xin), x, (size_t)B * S * S * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if ((rc = unet_conv1ch_fwd(x, B, S, PARAM(0), PARAM(1), ch[0], WS(pl.a1[0]), stream))) return rc;
+    {
+        RowScope rs(C11C, "fwd");
+        if (training) HIP_TRY(hipMemcpyAsync(WS(pl.xin), x, (size_t)B * S * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if ((rc = unet_conv1ch_fwd(x, B, S, PARAM(0), PARAM(1), ch[0], WS(pl.a1[0]), stream))) return rc;
+    }
     for (int l = 0; l < 5; ++l) {
         if (l > 0) {
+            RowScope rs(2 * l, "fwd");
             IgemmP p = conv_fwd_desc(WS(pl.t[l - 1]), pl.ein[l], pl.ein[l], ch[l - 1], 0, nullptr, 0, B, pl.ein[l], pl.ein[l],
                                      WS(pl.wt_fwd[2 * l]), PARAM(2 * (2 * l) + 1), ch[l], 1, WS(pl.a1[l]));
             WLayer L = wl_fwd(PARAM(2 * (2 * l)), ch[l], ch[l - 1], 0, WS(pl.wt_fwd[2 * l]));
             if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l]), L, 0, 0, st))) return rc;
             if ((rc = launch_igemm(p, st))) return rc;
         }
-        IgemmP p = conv_fwd_desc(WS(pl.a1[l]), pl.ea1[l], pl.ea1[l], ch[l], 0, nullptr, 0, B, pl.ea1[l], pl.ea1[l],
-                                 WS(pl.wt_fwd[2 * l + 1]), PARAM(2 * (2 * l + 1) + 1), ch[l], 1, WS(pl.a2[l]));
-        WLayer L2 = wl_fwd(PARAM(2 * (2 * l + 1)), ch[l], ch[l], 0, WS(pl.wt_fwd[2 * l + 1]));
-        if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l + 1]), L2, 0, 0, st))) return rc;
-        const bool pool_fused = l < 4 && p.wino_u && wino_fuses_pool(p);       // the Winograd epilogue writes t[l] too
-        if (pool_fused) p.pool_dst = WS(pl.t[l]);
-        if ((rc = launch_igemm(p, st))) return rc;
-        if (l < 4 && !pool_fused && (rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
+        bool pool_fused = false;
+        {
+            RowScope rs(2 * l + 1, "fwd");
+            IgemmP p = conv_fwd_desc(WS(pl.a1[l]), pl.ea1[l], pl.ea1[l], ch[l], 0, nullptr, 0, B, pl.ea1[l], pl.ea1[l],
+                                     WS(pl.wt_fwd[2 * l + 1]), PARAM(2 * (2 * l + 1) + 1), ch[l], 1, WS(pl.a2[l]));
+            WLayer L2 = wl_fwd(PARAM(2 * (2 * l + 1)), ch[l], ch[l], 0, WS(pl.wt_fwd[2 * l + 1]));
+            if ((rc = with_wino(p, WS(pl.wu_fwd[2 * l + 1]), L2, 0, 0, st))) return rc;
+            pool_fused = l < 4 && p.wino_u && wino_fuses_pool(p);       // the Winograd epilogue writes t[l] too
+            if (pool_fused) p.pool_dst = WS(pl.t[l]);
+            if ((rc = launch_igemm(p, st))) return rc;
+        }
+        if (l < 4 && !pool_fused) {
+            char nm[40]; snprintf(nm, sizeof(nm), "pool%d.fwd", l + 1);
+            ProfScope ps(nm);
+            if ((rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
+        }
     }
     // decoder (network.py:159-188): up-conv, virtual zero-pad-concat, two convs
     const float *dsrc = WS(pl.a2[4]);
     for (int l = 3; l >= 0; --l) {
         const int hin = pl.eu[l] / 2;
-        IgemmP u{};
-        u.nsrc = 1; u.src[0] = GSrc{dsrc, hin, hin, ch[l + 1], 0, ch[l + 1], 0};
-        u.wt = WS(pl.wt_fwd[UP_L[l]]); u.Kd = ch[l + 1];
-        u.T = 1; u.TX = 1; u.stride = 1;
-        u.NB = B; u.OH = hin; u.OW = hin; u.M = B * hin * hin; u.Nn = 4 * ch[l];
-        u.dst = WS(pl.u[l]); u.DH = pl.eu[l]; u.DW = pl.eu[l]; u.DC = ch[l]; u.scatter = 1; u.cout = ch[l];
-        u.bias = PARAM(2 * UP_L[l] + 1);
-        if ((rc = launch_igemm(u, st))) return rc;
-        WLayer L1 = wl_fwd(PARAM(2 * C1E_L[l]), ch[l], ch[l], ch[l], WS(pl.wt_fwd[C1E_L[l]]));
-        if ((rc = conv_fwd_launch(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l],
-                                  L1, PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st, WS(pl.wu_fwd[C1E_L[l]])))) return rc;
-        IgemmP c2 = conv_fwd_desc(WS(pl.d1[l]), pl.ed1[l], pl.ed1[l], ch[l], 0, nullptr, 0, B, pl.ed1[l], pl.ed1[l],
-                                  WS(pl.wt_fwd[C2E_L[l]]), PARAM(2 * C2E_L[l] + 1), ch[l], 1, WS(pl.d2[l]));
-        WLayer L2e = wl_fwd(PARAM(2 * C2E_L[l]), ch[l], ch[l], 0, WS(pl.wt_fwd[C2E_L[l]]));
-        if ((rc = with_wino(c2, WS(pl.wu_fwd[C2E_L[l]]), L2e, 0, 0, st))) return rc;
-        if ((rc = launch_igemm(c2, st))) return rc;
+        {
+            RowScope rs(UP_L[l], "fwd");
+            IgemmP u{};
+            u.nsrc = 1; u.src[0] = GSrc{dsrc, hin, hin, ch[l + 1], 0, ch[l + 1], 0};
+            u.wt = WS(pl.wt_fwd[UP_L[l]]); u.Kd = ch[l + 1];
+            u.T = 1; u.TX = 1; u.stride = 1;
+            u.NB = B; u.OH = hin; u.OW = hin; u.M = B * hin * hin; u.Nn = 4 * ch[l];
+            u.dst = WS(pl.u[l]); u.DH = pl.eu[l]; u.DW = pl.eu[l]; u.DC = ch[l]; u.scatter = 1; u.cout = ch[l];
+            u.bias = PARAM(2 * UP_L[l] + 1);
+            u.math = pl.math;
+            if ((rc = launch_igemm(u, st))) return rc;
+        }
+        {
+            RowScope rs(C1E_L[l], "fwd");
+            WLayer L1 = wl_fwd(PARAM(2 * C1E_L[l]), ch[l], ch[l], ch[l], WS(pl.wt_fwd[C1E_L[l]]));
+            if ((rc = conv_fwd_launch(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.u[l]), ch[l], B, pl.eu[l],
+                                      L1, PARAM(2 * C1E_L[l] + 1), ch[l], 1, WS(pl.d1[l]), st, WS(pl.wu_fwd[C1E_L[l]])))) return rc;
+        }
+        {
+            RowScope rs(C2E_L[l], "fwd");
+            IgemmP c2 = conv_fwd_desc(WS(pl.d1[l]), pl.ed1[l], pl.ed1[l], ch[l], 0, nullptr, 0, B, pl.ed1[l], pl.ed1[l],
+                                      WS(pl.wt_fwd[C2E_L[l]]), PARAM(2 * C2E_L[l] + 1), ch[l], 1, WS(pl.d2[l]));
+            WLayer L2e = wl_fwd(PARAM(2 * C2E_L[l]), ch[l], ch[l], 0, WS(pl.wt_fwd[C2E_L[l]]));
+            if ((rc = with_wino(c2, WS(pl.wu_fwd[C2E_L[l]]), L2e, 0, 0, st))) return rc;
+            if ((rc = launch_igemm(c2, st))) return rc;
+        }
         dsrc = WS(pl.d2[l]);
     }
-    if ((rc = unet_head1x1_fwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), PARAM(2 * FINAL + 1), logits, stream))) return rc;
+    {
+        RowScope rs(FINAL, "fwd");
+        if ((rc = unet_head1x1_fwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), PARAM(2 * FINAL + 1), logits, stream))) return rc;
+    }
     if (training) h->remember(workspace, pl);
     return 0;
 }
@@ -501,7 +582,7 @@ int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const ch
 {
     ARG_CHECK(h && name && offset && extent && channels, "unet_debug_buffer: null argument");
     Plan pl;
-    int rc = make_plan(pl, h->base_ch, B, S, training);
+    int rc = make_plan(pl, h->base_ch, B, S, training, handle_math(h));
     if (rc) return rc;
     char kind[16];
     int l = 0;
@@ -556,39 +637,20 @@ int unet_backward_stage_params(int stage, int *idx, int cap)
 
 #define GRAD(i) ((float *)grads[(i)])
 
-// Weight gradients of a backward stage go to `wst()`: the handle's auxiliary stream, made to wait for everything enqueued
-// on the main stream so far (dz is ready), or the main stream itself when overlap is off.
-struct WgradStream {
-    unet_handle *h; hipStream_t main; bool overlap; bool used = false;
-    hipStream_t operator()()
-    {
-        if (!overlap) return main;
-        (void)hipEventRecord(h->ev_fork, main);
-        (void)hipStreamWaitEvent(h->aux, h->ev_fork, 0);
-        used = true;
-        return h->aux;
-    }
-    void join()
-    {
-        if (!used) return;
-        (void)hipEventRecord(h->ev_join, h->aux);
-        (void)hipStreamWaitEvent(main, h->ev_join, 0);
-        used = false;
-    }
-};
-
-static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, WgradStream &wst, const void *const *params, void *const *grads,
+static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const void *const *params, void *const *grads,
                          int layer, const float *X, int XH, int C, const float *dz, int Ho, int K,
                          float *dx, const float *mask, const float *add)
 {
-    // single-source 3x3 conv: wgrad + bias grad (auxiliary stream), dgrad (optional)
+    // single-source 3x3 conv: wgrad + bias grad, dgrad (optional)
     const int B = pl.B;
     int rc;
     {
+        RowScope rs(layer, "wgrad");
         WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes, GRAD(2 * layer + 1));
-        if ((rc = launch_wgrad(w, wst()))) return rc;
+        if ((rc = launch_wgrad(w, st))) return rc;
     }
     if (dx) {
+        RowScope rs(layer, "dgrad");
         WLayer L = wl_dgrad(PARAM(2 * layer), K, C, WS(pl.wt_bwd[layer]));
         IgemmP d = conv_dgrad_desc(dz, Ho, Ho, K, B, XH, 0, WS(pl.wt_bwd[layer]), C, dx, mask, add);
         if ((rc = with_wino(d, WS(pl.wu_bwd[layer]), L, 0, 0, st))) return rc;
@@ -597,10 +659,18 @@ static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, WgradS
     return 0;
 }
 
+static int pool_backward(const Plan &pl, void *workspace, int l, void *stream)
+{
+    char nm[40]; snprintf(nm, sizeof(nm), "pool%d.bwd", l + 1);
+    ProfScope ps(nm);
+    return unet_maxpool2_bwd(WS(pl.a2[l]), WS(pl.g_t[l]), WS(pl.g_a2[l]), pl.B, pl.ea2[l], pl.ea2[l], pl.ch[l], stream);
+}
+
 int unet_backward_stage(unet_handle *h, int stage, const void *const *params, const void *dlogits, void *const *grads,
                         void *workspace, size_t workspace_bytes, void *stream)
 {
     ARG_CHECK(h && params && grads && workspace, "unet_backward: null argument");
+    CHECK_DEVICE(h, "unet_backward");
     Plan pl;
     if (!h->lookup(workspace, pl)) {
         set_error("unet_backward: no training forward has been run on this workspace");
@@ -609,35 +679,29 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
     ARG_CHECK(workspace_bytes >= pl.total, "unet_backward: workspace too small");
     if (pl.base % 64 != 0) { set_error("unet_backward: base_ch %d unsupported for training (needs a multiple of 64)", pl.base); return UNET_E_UNSUPPORTED; }
     ARG_CHECK(stage >= 0 && stage < N_STAGES, "unet_backward: bad stage %d", stage);
+    MathScope ms(pl.math);                   // the arithmetic the forward was planned with
     hipStream_t st = (hipStream_t)stream;
     const int B = pl.B;
     const int *ch = pl.ch;
     int rc;
-    static const int overlap = [] { const char *e = getenv("UNET_OVERLAP"); return e ? atoi(e) : 0; }();   // opt-in: +1 %
-    if (overlap && !h->aux) {
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
-    WgradStream wst{h, st, overlap != 0};
-    struct Joiner { WgradStream &w; ~Joiner() { w.join(); } } joiner{wst};      // every return path re-joins the streams
 
     if (stage < 4) {
         const int l = stage;
         if (l == 0) {
             ARG_CHECK(dlogits, "unet_backward: null dlogits");
             // finalconv backward, fused with the ReLU backward of conv12e -> dz of conv12e
+            RowScope rs(FINAL, "bwd");
             if ((rc = unet_head1x1_bwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), dlogits, WS(pl.g_d2[0]),
                                        GRAD(2 * FINAL), GRAD(2 * FINAL + 1), WS(pl.small), stream))) return rc;
         }
         // conv_l2e: input d1[l] (ReLU output of conv_l1e)
-        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, C2E_L[l], WS(pl.d1[l]), pl.ed1[l], ch[l], WS(pl.g_d2[l]), pl.ed2[l], ch[l],
+        if ((rc = conv_backward(pl, workspace, st, params, grads, C2E_L[l], WS(pl.d1[l]), pl.ed1[l], ch[l], WS(pl.g_d2[l]), pl.ed2[l], ch[l],
                                 WS(pl.g_d1[l]), WS(pl.d1[l]), nullptr))) return rc;
         // conv_l1e: virtual concat input.  dgrad per source half (skip half only over the crop window)
         const int lay = C1E_L[l];
         WLayer Ld = wl_dgrad(PARAM(2 * lay), ch[l], 2 * ch[l], WS(pl.wt_bwd[lay]));
         {
+            RowScope rs(lay, "dgrad");
             IgemmP ds = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.et[l], pl.pad[l],
                                         WS(pl.wt_bwd[lay]), ch[l], WS(pl.g_ts[l]), nullptr, nullptr);
             if ((rc = with_wino(ds, WS(pl.wu_bwd[lay]), Ld, 0, 0, st))) return rc;
@@ -648,12 +712,13 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             if ((rc = launch_igemm(du, st))) return rc;
         }
         {
+            RowScope rs(lay, "wgrad");
             WgradP ws_ = conv_wgrad_desc(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
                                          GRAD(2 * lay), 2 * ch[l], 0, WS(pl.slab), pl.slab_bytes);
-            if ((rc = launch_wgrad(ws_, wst()))) return rc;
+            if ((rc = launch_wgrad(ws_, st))) return rc;
             WgradP wu = conv_wgrad_desc(WS(pl.u[l]), pl.eu[l], ch[l], 0, WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
                                         GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes, GRAD(2 * lay + 1));
-            if ((rc = launch_wgrad(wu, wst()))) return rc;
+            if ((rc = launch_wgrad(wu, st))) return rc;
         }
         // upconv_l: input is d2[l+1] (or a2[4]); its dgrad is masked by that ReLU output
         {
@@ -661,40 +726,46 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             const int hin = pl.eu[l] / 2;
             const float *uin = l == 3 ? WS(pl.a2[4]) : WS(pl.d2[l + 1]);
             float *dzin = l == 3 ? WS(pl.g_a2[4]) : WS(pl.g_d2[l + 1]);
-            if ((rc = pack_upconv_dgrad(PARAM(2 * ul), WS(pl.wt_bwd[ul]), ch[l + 1], ch[l], st))) return rc;
-            IgemmP d{};
-            d.nsrc = 1; d.src[0] = GSrc{WS(pl.g_u[l]), pl.eu[l], pl.eu[l], ch[l], 0, ch[l], 0};
-            d.wt = WS(pl.wt_bwd[ul]); d.Kd = 4 * ch[l];
-            d.T = 4; d.TX = 2; d.stride = 2;
-            d.NB = B; d.OH = hin; d.OW = hin; d.M = B * hin * hin; d.Nn = ch[l + 1];
-            d.dst = dzin; d.DH = hin; d.DW = hin; d.DC = ch[l + 1];
-            d.mask = uin;
-            if ((rc = launch_igemm(d, st))) return rc;
+            {
+                RowScope rs(ul, "dgrad");
+                if ((rc = pack_upconv_dgrad(PARAM(2 * ul), WS(pl.wt_bwd[ul]), ch[l + 1], ch[l], st))) return rc;
+                IgemmP d{};
+                d.nsrc = 1; d.src[0] = GSrc{WS(pl.g_u[l]), pl.eu[l], pl.eu[l], ch[l], 0, ch[l], 0};
+                d.wt = WS(pl.wt_bwd[ul]); d.Kd = 4 * ch[l];
+                d.T = 4; d.TX = 2; d.stride = 2;
+                d.NB = B; d.OH = hin; d.OW = hin; d.M = B * hin * hin; d.Nn = ch[l + 1];
+                d.dst = dzin; d.DH = hin; d.DW = hin; d.DC = ch[l + 1];
+                d.mask = uin;
+                d.math = pl.math;
+                if ((rc = launch_igemm(d, st))) return rc;
+            }
+            RowScope rs(ul, "wgrad");
             WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes, GRAD(2 * ul + 1));
-            if ((rc = launch_wgrad(w, wst()))) return rc;
+            if ((rc = launch_wgrad(w, st))) return rc;
         }
         return 0;
     }
 
     if (stage == 4) {
-        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, C52C, WS(pl.a1[4]), pl.ea1[4], ch[4], WS(pl.g_a2[4]), pl.ea2[4], ch[4],
+        if ((rc = conv_backward(pl, workspace, st, params, grads, C52C, WS(pl.a1[4]), pl.ea1[4], ch[4], WS(pl.g_a2[4]), pl.ea2[4], ch[4],
                                 WS(pl.g_a1[4]), WS(pl.a1[4]), nullptr))) return rc;
-        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, C51C, WS(pl.t[3]), pl.ein[4], ch[3], WS(pl.g_a1[4]), pl.ea1[4], ch[4],
+        if ((rc = conv_backward(pl, workspace, st, params, grads, C51C, WS(pl.t[3]), pl.ein[4], ch[3], WS(pl.g_a1[4]), pl.ea1[4], ch[4],
                                 WS(pl.g_t[3]), nullptr, WS(pl.g_ts[3])))) return rc;
-        return unet_maxpool2_bwd(WS(pl.a2[3]), WS(pl.g_t[3]), WS(pl.g_a2[3]), B, pl.ea2[3], pl.ea2[3], ch[3], stream);
+        return pool_backward(pl, workspace, 3, stream);
     }
 
     // stage 5: encoder levels 3..0
     for (int l = 3; l >= 0; --l) {
-        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, 2 * l + 1, WS(pl.a1[l]), pl.ea1[l], ch[l], WS(pl.g_a2[l]), pl.ea2[l], ch[l],
+        if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l + 1, WS(pl.a1[l]), pl.ea1[l], ch[l], WS(pl.g_a2[l]), pl.ea2[l], ch[l],
                                 WS(pl.g_a1[l]), WS(pl.a1[l]), nullptr))) return rc;
         if (l == 0) {
             // conv11c: weight/bias gradient only (A1 needs no dgrad)
+            RowScope rs(C11C, "wgrad");
             return unet_conv1ch_bwd(WS(pl.xin), B, pl.S, ch[0], WS(pl.g_a1[0]), GRAD(0), GRAD(1), WS(pl.small), stream);
         }
-        if ((rc = conv_backward(pl, workspace, st, wst, params, grads, 2 * l, WS(pl.t[l - 1]), pl.ein[l], ch[l - 1], WS(pl.g_a1[l]), pl.ea1[l], ch[l],
+        if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l, WS(pl.t[l - 1]), pl.ein[l], ch[l - 1], WS(pl.g_a1[l]), pl.ea1[l], ch[l],
                                 WS(pl.g_t[l - 1]), nullptr, WS(pl.g_ts[l - 1])))) return rc;
-        if ((rc = unet_maxpool2_bwd(WS(pl.a2[l - 1]), WS(pl.g_t[l - 1]), WS(pl.g_a2[l - 1]), B, pl.ea2[l - 1], pl.ea2[l - 1], ch[l - 1], stream))) return rc;
+        if ((rc = pool_backward(pl, workspace, l - 1, stream))) return rc;
     }
     return 0;
 }
@@ -714,12 +785,27 @@ int unet_backward(unet_handle *h, const void *const *params, const void *dlogits
 static size_t conv_bwd_slab_bound(int B, int H, int C, int K)
 {
     size_t need = 0;
-    for (int ci = 64; ci <= (C + 63) / 64 * 64; ci *= 2) {
-        WgradP w = conv_wgrad_desc(nullptr, H, ci, 0, nullptr, H - 2, K, B, nullptr, ci, 0, nullptr, 0);
+    for (int math = 0; math <= 2; math += 2) {          // the decomposition differs between the fp32 and the bf16 kernels
+        MathScope ms(math);
+        for (int ci = 64; ci <= (C + 63) / 64 * 64; ci *= 2) {
+            WgradP w = conv_wgrad_desc(nullptr, H, ci, 0, nullptr, H - 2, K, B, nullptr, ci, 0, nullptr, 0);
+            const size_t n = wgrad_slab_need(w);
+            if (n > need) need = n;
+        }
+    }
+    return align_up(2 * need, 256);
+}
+
+static size_t upconv_slab_bound(int B, int H, int Ci, int Co)
+{
+    size_t need = 0;
+    for (int math = 0; math <= 2; math += 2) {
+        MathScope ms(math);
+        WgradP w = upconv_wgrad_desc(nullptr, H, Ci, nullptr, Co, B, nullptr, nullptr, 0);
         const size_t n = wgrad_slab_need(w);
         if (n > need) need = n;
     }
-    return align_up(2 * need, 256);
+    return align_up(need, 256);
 }
 
 // ---- per-op entry points (unit tests) --------------------------------------------------------------
@@ -729,6 +815,8 @@ int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
                      const void *w_oihw, const void *bias, int K, int relu, void *y, void *scratch, void *stream)
 {
     ARG_CHECK(x1 && w_oihw && y && scratch, "conv3x3_fwd: null argument");
+    MathScope ms(get_math_mode());
+    ProfScope ps("op.conv3x3_fwd");
     ARG_CHECK(x2 || (H1 + 2 * pad1 == H && W1 + 2 * pad1 == W), "conv3x3_fwd: single source must match the input extent");
     hipStream_t st = (hipStream_t)stream;
     ARG_CHECK(H == W && H1 == W1, "conv3x3_fwd: square tiles only");
@@ -749,6 +837,8 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
                      void *dx2, const void *mask2, void *dw, void *db, void *scratch, void *stream)
 {
     ARG_CHECK(x1 && w_oihw && dz && scratch, "conv3x3_bwd: null argument");
+    MathScope ms(get_math_mode());
+    ProfScope ps("op.conv3x3_bwd");
     ARG_CHECK(H == W && H1 == W1, "conv3x3_bwd: square tiles only");
     hipStream_t st = (hipStream_t)stream;
     const int C = C1 + (x2 ? C2 : 0);
@@ -794,8 +884,7 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
 size_t unet_upconv2_scratch_bytes(int B, int H, int W, int Ci, int Co)
 {
     (void)W;
-    WgradP w = upconv_wgrad_desc(nullptr, H, Ci, nullptr, Co, B, nullptr, nullptr, 0);
-    return align_up((size_t)Ci * Co * 4 * sizeof(float), 256) + align_up(wgrad_slab_need(w), 256) +
+    return align_up((size_t)Ci * Co * 4 * sizeof(float), 256) + upconv_slab_bound(B, H, Ci, Co) +
            align_up(bias_grad_scratch_bytes((size_t)B * 4 * H * W, Co), 256);
 }
 
@@ -803,6 +892,8 @@ int unet_upconv2_fwd(const void *x, int B, int H, int W, int Ci, const void *w_i
                      void *y, void *scratch, void *stream)
 {
     ARG_CHECK(x && w_iohw && y && scratch, "upconv2_fwd: null argument");
+    MathScope ms(get_math_mode());
+    ProfScope ps("op.upconv2_fwd");
     hipStream_t st = (hipStream_t)stream;
     int rc = pack_upconv_fwd((const float *)w_iohw, (float *)scratch, Ci, Co, st);
     if (rc) return rc;
@@ -813,6 +904,7 @@ int unet_upconv2_fwd(const void *x, int B, int H, int W, int Ci, const void *w_i
     u.NB = B; u.OH = H; u.OW = W; u.M = B * H * W; u.Nn = 4 * Co;
     u.dst = (float *)y; u.DH = 2 * H; u.DW = 2 * W; u.DC = Co; u.scatter = 1; u.cout = Co;
     u.bias = (const float *)bias;
+    u.math = t_math;
     return launch_igemm(u, st);
 }
 
@@ -821,11 +913,12 @@ int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_i
 {
     ARG_CHECK(x && w_iohw && dy && scratch, "upconv2_bwd: null argument");
     ARG_CHECK(H == W, "upconv2_bwd: square tiles only");
+    MathScope ms(get_math_mode());
+    ProfScope ps("op.upconv2_bwd");
     hipStream_t st = (hipStream_t)stream;
     float *wt = (float *)scratch;
     const size_t wt_bytes = align_up((size_t)Ci * Co * 4 * sizeof(float), 256);
-    WgradP sizing = upconv_wgrad_desc(nullptr, H, Ci, nullptr, Co, B, nullptr, nullptr, 0);
-    const size_t slab_bytes = align_up(wgrad_slab_need(sizing), 256);
+    const size_t slab_bytes = upconv_slab_bound(B, H, Ci, Co);
     float *slab = (float *)((char *)scratch + wt_bytes);
     float *small = (float *)((char *)scratch + wt_bytes + slab_bytes);
     int rc;
@@ -838,6 +931,7 @@ int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_i
         d.NB = B; d.OH = H; d.OW = W; d.M = B * H * W; d.Nn = Ci;
         d.dst = (float *)dx; d.DH = H; d.DW = W; d.DC = Ci;
         d.mask = (const float *)mask;
+        d.math = t_math;
         if ((rc = launch_igemm(d, st))) return rc;
     }
     if (dw) {

@@ -297,7 +297,7 @@ static void decompose(const WgradP &p, WgradK &k)
     // Choose rows-per-chunk r and ngroups to minimise  rounds(ngroups*ntile / resident slots) x ceil(nparts/ngroups) x r
     // (all workgroups of a launch do the same per-row work), preferring fewer groups (slab traffic) on ties.
     const int ntile = k.ntile_i * k.ntile_j;
-    const int slots = 256 * ((p.TY == 3 && (get_math_mode() == 0 || get_math_mode() == 3)) ? 3 : 2);
+    const int slots = 256 * ((p.TY == 3 && (p.math == 0 || p.math == 3)) ? 3 : 2);
     const long per_chunk = (long)p.NB * k.nstrips;
     // the search is a few million cheap iterations: memoise per shape (hot calls hit the cache)
     static std::mutex mu;
@@ -354,9 +354,7 @@ size_t wgrad_slab_need(const WgradP &p)
     return a > b ? a : b;
 }
 
-double wgrad_alg_flops_pub(const WgradP &p);
-static double wgrad_alg_flops(const WgradP &p) { return wgrad_alg_flops_pub(p); }
-double wgrad_alg_flops_pub(const WgradP &p)
+double wgrad_alg_flops(const WgradP &p)
 {
     long cy = 0, cx = 0;
     for (int y = 0; y < p.YH; ++y)
@@ -364,6 +362,20 @@ double wgrad_alg_flops_pub(const WgradP &p)
     for (int x = 0; x < p.YW; ++x)
         for (int t = 0; t < p.TX; ++t) { const int i = (x + p.ox0) * p.stride - p.xpad + t; cx += (i >= 0 && i < p.XW); }
     return 2.0 * p.NB * (double)cy * (double)cx * p.Ci * p.Cj;
+}
+
+// algorithmic HBM bytes: the X pixels the window's taps reach and the Y window, once each; the gradient tensor, once
+double wgrad_alg_bytes(const WgradP &p)
+{
+    int y0 = (p.ywin0 + p.oy0) * p.stride - p.xpad, y1 = (p.ywin1 - 1 + p.oy0) * p.stride - p.xpad + p.TY;
+    int x0 = (p.xwin0 + p.ox0) * p.stride - p.xpad, x1 = (p.xwin1 - 1 + p.ox0) * p.stride - p.xpad + p.TX;
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > p.XH ? p.XH : y1; x1 = x1 > p.XW ? p.XW : x1;
+    double b = 0.0;
+    if (y1 > y0 && x1 > x0) b += (double)p.NB * (y1 - y0) * (x1 - x0) * p.Ci * 4.0;
+    b += (double)p.NB * (p.ywin1 - p.ywin0) * (p.xwin1 - p.xwin0) * p.Cj * 4.0;
+    b += (double)p.TY * p.TX * p.Ci * p.Cj * 4.0;
+    return b;
 }
 
 template <int TY, int TX, int S, int NSPLIT>
@@ -376,7 +388,12 @@ static int launch_wgrad_t(const WgradK &k, hipStream_t st)
     char tag[96];
     snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d;split%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, NSPLIT, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
              k.p.ywin1 - k.p.ywin0, k.nparts, k.pw, k.rows_per_chunk, k.ngroups);
-    prof_begin(1, wgrad_alg_flops(k.p), st, tag);
+    {
+        // executed: every workgroup runs its partitions' rows x pixel pairs (NSPLIT 0) / 16-pixel groups for all taps of a 64x64 tile
+        const double rows = (double)k.p.NB * (k.p.ywin1 - k.p.ywin0) * k.nstrips;
+        const double kpix = NSPLIT == 0 ? 2.0 * ((k.pw + 1) / 2) : 16.0 * ((k.pw + 15) / 16);
+        prof_begin(PK_WGRAD, tag, st, wgrad_alg_flops(k.p), 2.0 * rows * kpix * G::T * k.p.Ci * k.p.Cj * (NSPLIT == 3 ? 3 : 1), wgrad_alg_bytes(k.p));
+    }
     hipLaunchKernelGGL(kern, dim3(k.ngroups * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
     prof_end(st);
     HIP_TRY(hipGetLastError());
@@ -391,8 +408,10 @@ int launch_wgrad(WgradP p, hipStream_t st)
     ARG_CHECK((size_t)p.NB * p.XH * p.XW * p.XC < 0x7FFFFFFFull * 2 && (size_t)p.NB * p.YH * p.YW * p.YC < 0x7FFFFFFFull * 2, "wgrad: tensor too large");
     p.zeros = zero_page();
     if (!p.zeros) return -2;
-    static const int ww = [] { const char *e = getenv("UNET_WGRADW"); return e ? atoi(e) : 1; }();
-    if (get_math_mode() == 3 && ww && wgradw_applicable(p)) return launch_wgradw(p, st);     // Winograd F(3x3 <- 2x2) (wgradw.hip)
+    ARG_CHECK(p.math >= 0 && p.math <= 3, "wgrad: bad arithmetic mode %d", p.math);
+    if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");
+    if (p.db && p.db_on_x) ARG_CHECK(p.stride == p.TY && p.stride == p.TX && p.xpad == 0, "wgrad: bias-on-X needs stride == taps (every X pixel staged exactly once)");
+    if (p.math == 3 && wgradw_applicable(p)) return launch_wgradw(p, st);     // Winograd F(3x3 <- 2x2) (wgradw.hip)
     WgradK k{};
     k.p = p;
     decompose(p, k);
@@ -401,20 +420,18 @@ int launch_wgrad(WgradP p, hipStream_t st)
     const size_t need = (size_t)nP * k.pstride * sizeof(float);
     ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
     int rc;
-    const int mode = get_math_mode() == 3 ? 0 : get_math_mode();     // mode 3 (Winograd) only changes the igemm side
+    const int mode = p.math == 3 ? 0 : p.math;     // mode 3 (Winograd) falls back to the exact fp32 kernel for the shapes wgradw.hip does not take
     if (p.TY == 3 && p.TX == 3 && p.stride == 1)
         rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_t<3, 3, 1, 1>(k, st);
     else if (p.TY == 2 && p.TX == 2 && p.stride == 2)
         rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_t<2, 2, 2, 1>(k, st);
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
-    if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");
-    if (p.db && p.db_on_x) ARG_CHECK(p.stride == p.TY && p.stride == p.TX && p.xpad == 0, "wgrad: bias-on-X needs stride == taps (every X pixel staged exactly once)");
     const int ndb = p.db ? (p.db_on_x ? p.Ci : p.Cj) : 0;
     const size_t total = (size_t)T * p.Ci * p.Cj + ndb;
     size_t blocks = (total + 63) / 64;
     if (blocks > 16384) blocks = 16384;
-    prof_begin(2, 0.0, st);
+    prof_begin(PK_REDUCE, "wgrad_reduce", st, 0.0, 0.0, (double)nP * k.pstride * 4.0 + (double)total * 4.0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st, p.db, ndb);
     prof_end(st);
     HIP_TRY(hipGetLastError());

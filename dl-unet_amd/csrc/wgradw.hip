@@ -53,39 +53,11 @@ constexpr int WW_SLAB = 16 * 64 * 64 + 64;                  // dU partial + bias
 
 template <int N> __device__ __forceinline__ void ww_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ f32x2 wpk_add(f32x2 a, f32x2 b)
-{
-#ifdef WW_ASM_PK
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a + b;
-#endif
-}
-__device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b)
-{
-#ifdef WW_ASM_PK
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a - b;
-#endif
-}
+// plain float2 arithmetic (selected as v_pk_add_f32; inline asm would hide the VALU->MFMA hazards from the compiler)
+__device__ __forceinline__ f32x2 wpk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 wpk_sub(f32x2 a, f32x2 b) { return a - b; }
 
-// N x { 1 MFMA, then VALU_ VALU and DS_ LDS-read instructions }: the order imposed on the scheduling region that ends here
-template <int N, int VALU_, int DS_> __device__ __forceinline__ void ww_interleave()
-{
-    if constexpr (N > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (DS_ > 0) __builtin_amdgcn_sched_group_barrier(0x100, DS_, 0);
-        if constexpr (VALU_ > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_, 0);
-        ww_interleave<N - 1, VALU_, DS_>();
-    }
-}
-
-template <int DBG, bool SCHED, bool BUF>
+template <bool BUF>
 __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
 {
     const WgradP &p = k.p;
@@ -296,10 +268,10 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
         // instruction issue then overlaps the partner's MFMAs
         const bool early = wave < 4;
         for (int s = 0; s < ns; ++s) {
-            const bool more = s + 2 < ns && DBG != 1;
+            const bool more = s + 2 < ns;
             const int buf = s % WW_NST;
             if (more && early) stage((s + 2) % WW_NST, s0 + s + 2);
-            if (DBG != 2) {
+            {
                 // software pipeline inside the step: the operands of the next 32 MFMAs are read and transformed in the
                 // shadow of the current 32 (each MFMA leaves 24 of its 32 cycles of vector issue free)
                 f32x2 va[16], vb[16], za[16], zb[16];
@@ -308,22 +280,19 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
                 __builtin_amdgcn_sched_barrier(0);
                 mfma32(va, za, 0);
                 load_z(buf, 0, 1, zb);
-                if (SCHED) ww_interleave<18, 1, 0>();
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma32(va, zb, 1);
                 load_v(buf, 1, vb);
-                if (SCHED) ww_interleave<32, 1, 1>();
                 __builtin_amdgcn_sched_barrier(0);
                 load_z(buf, 1, 0, za);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma32(vb, za, 0);
                 load_z(buf, 1, 1, zb);
-                if (SCHED) ww_interleave<18, 1, 0>();
                 __builtin_amdgcn_sched_barrier(0);
                 mfma32(vb, zb, 1);
-            } else if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
+            }
             wait_landed(more);
             __builtin_amdgcn_s_barrier();
         }
@@ -449,18 +418,13 @@ size_t wgradw_slab_need(const WgradP &p)
     return (size_t)k.ntile_i * k.ntile_j * k.nsplit * k.pstride * sizeof(float);
 }
 
-double wgrad_alg_flops_pub(const WgradP &p);
-
 int launch_wgradw(const WgradP &p, hipStream_t st)
 {
-    static const int dbg = [] { const char *e = getenv("UNET_WW_DBG"); return e ? atoi(e) : 0; }();
-    static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
     const size_t xb = (size_t)p.NB * p.XH * p.XW * p.XC * sizeof(float), yb = (size_t)p.NB * p.YH * p.YW * p.YC * sizeof(float);
-    const bool buf = usebuf && xb < 0x7FFFFFFFull && yb < 0x7FFFFFFFull;
-    auto kern = dbg == 1 ? wgradw_f32_kernel<1, false, false> : dbg == 2 ? wgradw_f32_kernel<2, false, false> : dbg == 3 ? wgradw_f32_kernel<0, true, false>
-              : buf ? wgradw_f32_kernel<0, false, true> : wgradw_f32_kernel<0, false, false>;
-    static bool attr_done[5][64] = {{false}};
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, WW_LDS, attr_done[dbg >= 1 && dbg <= 3 ? dbg : buf ? 4 : 0])) return rc_;
+    const bool buf = get_lds_dma_mode() != 0 && xb < 0x7FFFFFFFull && yb < 0x7FFFFFFFull;
+    auto kern = buf ? wgradw_f32_kernel<true> : wgradw_f32_kernel<false>;
+    static bool attr_done[2][64] = {{false}};
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, WW_LDS, attr_done[buf ? 1 : 0])) return rc_;
     WgradWK k;
     int cus = ww_cus();
     if (cus > 256) cus = 256;
@@ -473,12 +437,12 @@ int launch_wgradw(const WgradP &p, hipStream_t st)
               "wgradw: tensor exceeds 31-bit element offsets");
     if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgradw: fused bias gradient needs the full Y window");
     char tag[96];
-    snprintf(tag, sizeof(tag), "wgradw Ci=%d Cj=%d Y=%dx%d tiles=%dx%d steps=%d split=%d", p.Ci, p.Cj, p.YH, p.YW, k.TYn, k.TXn, k.nsteps, k.nsplit);
-    prof_begin(1, wgrad_alg_flops_pub(p), st, tag);
+    snprintf(tag, sizeof(tag), "wgradw<%d> Ci=%d Cj=%d Y=%dx%d tiles=%dx%d steps=%d split=%d", (int)buf, p.Ci, p.Cj, p.YH, p.YW, k.TYn, k.TXn, k.nsteps, k.nsplit);
+    prof_begin(PK_WGRAD, tag, st, wgrad_alg_flops(p), 2.0 * k.nsteps * 16.0 * 16.0 * p.Ci * p.Cj, wgrad_alg_bytes(p));
     hipLaunchKernelGGL(kern, dim3(ntile * k.nsplit), dim3(512), WW_LDS, st, k);
     prof_end(st);
     HIP_TRY(hipGetLastError());
-    prof_begin(2, 0.0, st);
+    prof_begin(PK_REDUCE, "wgradw_reduce", st, 0.0, 0.0, (double)ntile * k.nsplit * k.pstride * 4.0 + 9.0 * p.Ci * p.Cj * 4.0);
     hipLaunchKernelGGL(wgradw_reduce_kernel, dim3(ntile * 64), dim3(256), 0, st, p.slab, k.nsplit, k.pstride, k.ntile_j,
                        p.out, p.si, p.sj, p.st, p.db, p.yc0);
     prof_end(st);

@@ -7,16 +7,16 @@
 // All arithmetic is fp32 (v_mfma_f32_16x16x4_f32 + fp32 adds); only the evaluation order differs from the
 // direct correlation, which costs ~1e-6 relative (tests/test_ops_gpu.py pins it against the oracle).
 //
-// Work decomposition — a workgroup owns 64 Winograd tiles x 32 (wino32_f32_kernel, default: 256 threads, two workgroups
-// per CU) or x 64 (wino_f32_kernel: 512 threads, one per CU) output channels; a wave owns 16 tiles x 32 channels for
-// all 16 xi -> 16*2 accumulators of 16x16 (128 VGPRs):
+// Work decomposition — a 256-thread workgroup owns 64 Winograd tiles x 32 output channels, two workgroups per CU (their
+// set-up, first-stage latency, epilogue and barrier stalls hide behind each other's MFMAs); a wave owns 16 tiles x 32
+// channels for all 16 xi -> 16*2 accumulators of 16x16 (128 VGPRs):
 //   * tiles are numbered linearly over (image, tile row, tile column): no 2-D edge waste, only the last workgroup
 //     of a launch is ragged;
 //   * per K step (8 channels) the workgroup stages by LDS-DMA (buffer descriptors: fixed per-lane offsets, the channel
 //     step in the scalar offset, pixels outside the tensor through the range check)  (a) an 18 KiB patch image — each
 //     tile's two own pixel columns; columns 2,3 are the right neighbour's, or a per-tile-row "tail" — and (b) the
-//     16 / 32 KiB block of its channels' transformed filters U, which wino_transform_ref_kernel wrote in LDS/fragment
-//     order; 2-deep (wino32) or two 3-deep (wino) rings, one barrier per step;
+//     16 KiB block of its channels' transformed filters U, which wino_transform_ref_kernel wrote in LDS/fragment
+//     order; 2-deep rings, one barrier per step;
 //   * the INPUT transform is done in registers: lane (tile, kg) reads its 16 pixels x 2 channels (ds_read_b64,
 //     conflict-free layout), 32 packed adds give V[xi] for those 2 channels = exactly the A operands of the 16x16x4
 //     MFMAs (k index = kg); V never exists in memory;
@@ -26,12 +26,12 @@
 //     a max-pool, the pooled tensor as well (a tile is one pooling window).
 //
 // Why this shape: accumulators are 16x the output tile, so the tile is small and the staged bytes per MFMA cycle are
-// what a step has to hide: 34 KiB (wino32) per 64 MFMAs per wave.  DESIGN.md section 4 has the history and the numbers.
+// what a step has to hide: 34 KiB per 64 MFMAs per wave.  DESIGN.md section 4 has the history (a 512-thread, 64-channel
+// wide, one-per-CU variant with 3-deep rings was measured slower or equal on every launch of the net and removed).
 #include "common.hpp"
 #include "igemm_epilogue.hpp"
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
 
 namespace unet {
 
@@ -53,56 +53,14 @@ struct WinoP {
 
 
 // --------------------------------------------------------------------------------------------------------
-// U = G g G^T for every (n, c), written in the order the main kernel stages and reads it:
+// U = G g G^T for every (n, c), straight from the reference's OIHW weights, written in the order the main kernel
+// stages and reads it:
 //   block (nt = n/64, step = c/8)  [32 KiB]:  piece (n16 = (n/16)%4, xg = xi/4, h = c%2) [1 KiB]:
 //   lane (kg = (c%8)/2, nl = n%16) [16 B]: xi%4
-// Source: packed igemm weights wt[n][ldw], column = base(src) + tap*nch(src) + c  (pack_conv_fwd / pack_conv_dgrad).
-// --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino_transform_kernel(const float *__restrict__ wt, int ldw, int Nn, int nch0, int nch1,
-                                                             float *__restrict__ U)
-{
-    const int Kc = nch0 + nch1;
-    const size_t total = (size_t)Nn * Kc;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int n = (int)(idx / Kc), c = (int)(idx - (size_t)n * Kc);
-    const float *row = wt + (size_t)n * ldw;
-    int base, nch, cc;
-    if (c < nch0) { base = 0; nch = nch0; cc = c; } else { base = 9 * nch0; nch = nch1; cc = c - nch0; }
-    float g[3][3];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = row[base + t * nch + cc];
-    float r[4][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        r[0][j] = g[0][j];
-        r[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
-        r[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
-        r[3][j] = g[2][j];
-    }
-    float u[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        u[4 * i + 0] = r[i][0];
-        u[4 * i + 1] = 0.5f * (r[i][0] + r[i][1] + r[i][2]);
-        u[4 * i + 2] = 0.5f * (r[i][0] - r[i][1] + r[i][2]);
-        u[4 * i + 3] = r[i][2];
-    }
-    const int nsteps = Kc >> 3;
-    const int nt = n >> 6, n16 = (n >> 4) & 3, nl = n & 15;
-    const int step = c >> 3, kk = c & 7, kg = kk >> 1, h = kk & 1;
-    float *blk = U + ((size_t)nt * nsteps + step) * 8192;
-#pragma unroll
-    for (int xg = 0; xg < 4; ++xg) {
-        f32x4 v = {u[4 * xg], u[4 * xg + 1], u[4 * xg + 2], u[4 * xg + 3]};
-        *(f32x4 *)(blk + ((n16 * 4 + xg) * 2 + h) * 256 + (kg * 16 + nl) * 4) = v;
-    }
-}
-
-// The same U, straight from the reference's OIHW weights (no packed copy needed):
 //   forward  (dgrad = 0): filter matrix row n = output channel n0 + n, column k = input channel k0 + k, taps as stored
 //   dgrad    (dgrad = 1): row n = INPUT channel n0 + n, column k = output channel k0 + k, taps flipped (index 8 - t)
 // Thread order keeps the 36-byte reads of neighbouring threads adjacent (k fastest forward, n fastest dgrad).
+// --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wino_transform_ref_kernel(const float *__restrict__ w, int I, int dgrad, int n0, int Nn, int k0, int Kc,
                                                                  float *__restrict__ U)
 {
@@ -153,23 +111,13 @@ int wino_transform_ref(const float *w_oihw, int I, int dgrad, int n0, int Nn, in
     return 0;
 }
 
-int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *U, hipStream_t st)
-{
-    ARG_CHECK(wt && U && Nn % 64 == 0 && nch0 % 8 == 0 && nch1 % 8 == 0 && nch0 > 0, "wino_transform: bad shape");
-    const size_t total = (size_t)Nn * (nch0 + nch1);
-    hipLaunchKernelGGL(wino_transform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wt, ldw, Nn, nch0, nch1, U);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 // --------------------------------------------------------------------------------------------------------
-// LDS: [3 x patch stage 18 KiB][3 x U block 32 KiB] = 150 KiB, two independent 3-deep rings.
+// LDS of a workgroup: [2 x patch stage 18 KiB][2 x U block 16 KiB] = 68 KiB (+ row tables), two workgroups per CU.
 //   patch stage  [qy 4][par 2][idx 72][slot 2][16 B]:  idx < 64: pixel (qy, qx = par) of tile idx; idx = 64 + j: pixel
 //                (qy, qx = 2 + par) of "tail" j; slot = half ^ ((idx>>3)&1) holds channels 4*half..+3 of the step.
 //                The two halves of a pixel are adjacent lanes of one LDS-DMA instruction (one 32-B access instead of
-//                two cache-line lookups: the L1 processes about one line per clock, measured 61 cycles for a
-//                64-line instruction); the slot swizzle keeps the ds_read_b64 of 16 tiles on 64 distinct banks.
-//   U block      [n16 4][xg 4][h 2][lane 64][16 B]
+//                two cache-line lookups); the slot swizzle keeps the ds_read_b64 of 16 tiles on 64 distinct banks.
+//   U block      [n16 2][xg 4][h 2][lane 64][16 B]
 // A tile's columns 2,3 are its right neighbour's columns 0,1 — tiles are numbered linearly over (image, tile row,
 // tile column), so the neighbour is tile+1 except at the end of a tile row (or of the workgroup's 64 tiles), where
 // the two pixels come from tail j = (tile row) - (tile row of the workgroup's first tile).  That halves the patch
@@ -177,452 +125,14 @@ int wino_transform(const float *wt, int ldw, int Nn, int nch0, int nch1, float *
 // instructions (1 KiB each, lane-linear); a lane derives (row, idx) from its byte position.
 constexpr int WINO_ROW = 72 * 32;                       // 2304 B per (qy, par)
 constexpr int WINO_PATCH = 8 * WINO_ROW;                // 18432
-constexpr int WINO_NST = 3;
-constexpr int WINO_UBASE = WINO_NST * WINO_PATCH;
-constexpr int WINO_LDS = WINO_UBASE + WINO_NST * 32768;  // 153600 (the epilogue reuses 66.25 KiB of it)
 
 template <int N> __device__ __forceinline__ void wino_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
-{
-    return a + b;      // selected as v_pk_add_f32 (inline asm here hid the VALU->MFMA hazards from the compiler)
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
-{
-    return a - b;
-}
-
-template <int DBG, bool BUF>
-__global__ __launch_bounds__(512, 1) void wino_f32_kernel(const WinoP k)
-{
-    const IgemmP &p = k.p;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, kg = lane >> 4;
-    const int tpi = k.tiles_x * k.tiles_y;
-    const int ns = k.nsteps;
-    const bool early = wave < 4;
-
-    // ---- one (N tile, M tile) per workgroup.  XCD-aware order: every XCD (blockIdx & 7) gets a contiguous run of logical
-    // tiles; M tiles of one N tile are neighbours (they share the 32 KiB/step U stream, twice the patch bytes).
-    int slot;
-    {
-        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
-        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-
-    // ---- per-tile state
-    int T0 = 0, n0 = 0, R0 = 0;
-    constexpr int NPI = 3;
-    const int npi = wave < 2 ? 3 : 2;
-    int poff[NPI];                 // LDS-DMA source element offsets of this lane's patch instructions, -1 = zeros
-    int *poff1 = (int *)(smem + WINO_LDS + 1280) + tid;   // ... of the second source, parked in LDS: [ii][tid]
-    const float *sp = nullptr;
-    int snch = 0, kc = 0, pissued = 0;
-    const float *ublk = nullptr;
-    int offB = 0;
-
-    // read role: lane (tile = 16*wm + l15, kg): channels 2kg, 2kg+1 of the step = bytes (kg&1)*8 of half kg>>1.
-    // Pixel (qy, qx): qx < 2 at offA + (2*qy + qx)*ROW;  qx >= 2 at offB + (2*qy + qx - 2)*ROW.
-    const int tl = wm * 16 + l15;
-    const int offA = tl * 32 + (((kg >> 1) ^ ((tl >> 3) & 1)) * 16) + (kg & 1) * 8;
-    const int b_rd = WINO_UBASE + (2 * wn) * 8192 + lane * 16;
-
-    auto setup_tile = [&](int logical) {
-        const int nt = logical / p.mtiles, mt = logical - nt * p.mtiles;
-        T0 = mt * 64; n0 = nt * 64;
-        R0 = fdiv(T0, k.d_tx);                     // global tile row (image * tiles_y + ty) of the first tile
-        // DMA role: patch instructions i = wave, wave + 8 and (waves 0,1) wave + 16
-#pragma unroll
-        for (int ii = 0; ii < NPI; ++ii) {
-            const int pos = (wave + 8 * ii) * 1024 + lane * 16;
-            const int row = pos / WINO_ROW;
-            const int rem = pos - row * WINO_ROW;
-            const int idx = rem >> 5;
-            const int qy = row >> 1, par = row & 1, half = ((rem >> 4) & 1) ^ ((idx >> 3) & 1);
-            int T, qx;
-            bool ok = true;
-            if (idx < 64) {
-                T = T0 + idx; qx = par;
-            } else {
-                const int j = idx - 64;
-                ok = (R0 + j) * k.tiles_x <= T0 + 63;        // tile row R0 + j starts inside the workgroup's range
-                T = (R0 + j + 1) * k.tiles_x - 1;            // its last tile ...
-                T = T < T0 + 63 ? T : T0 + 63;               // ... or the workgroup's last tile
-                qx = 2 + par;
-            }
-            T = T < k.MT ? T : k.MT - 1;
-            const int img = fdiv(T, k.d_tpi);
-            const int trem = T - img * tpi;
-            const int ty = fdiv(trem, k.d_tx);
-            const int tx = trem - ty * k.tiles_x;
-#pragma unroll
-            for (int si = 0; si < 2; ++si) {
-                int o = -1;
-                if (si < p.nsrc && ii < npi) {
-                    const GSrc &g = p.src[si];
-                    const int iy = 2 * ty + p.oy0 - g.pad + qy, ix = 2 * tx + p.ox0 - g.pad + qx;
-                    const bool inb = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                    o = inb ? ((img * g.H + iy) * g.W + ix) * g.C + g.c0 + 4 * half : -1;
-                }
-                if (si == 0) poff[ii] = o; else if (p.nsrc > 1) poff1[ii * 512] = o;
-            }
-        }
-        if (BUF) {
-#pragma unroll
-            for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff[ii] >= 0 ? poff[ii] * 4 : (int)0x80000000;
-        }
-        sp = p.src[0].p; snch = p.src[0].nch; kc = 0; pissued = 0;
-        ublk = k.U + (size_t)nt * ns * 8192 + (4 * wave) * 256 + lane * 4;
-        {
-            const int T = T0 + tl;
-            const int R = fdiv(T, k.d_tx);
-            const bool rowend = (T - R * k.tiles_x == k.tiles_x - 1) || tl == 63;
-            int j = R - R0;
-            j = j < 7 ? j : 7;
-            const int idxB = rowend ? 64 + j : tl + 1;
-            offB = idxB * 32 + (((kg >> 1) ^ ((idxB >> 3) & 1)) * 16) + (kg & 1) * 8;
-        }
-    };
-
-    // Per batch a wave issues 2 (+1 for waves 0,1) patch instructions and 4 U instructions: the vmcnt waits count on it.
-    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): fixed per-lane byte offsets, the channel
-    // step in the scalar offset, out-of-tensor pixels as offsets beyond num_records (zeros) - no per-step address VALU.
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, BUF ? k.xbytes[0] : 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)k.U, 0, BUF ? k.ubytes : 0, 0x00020000);
-    const int u_voff = ((4 * wave) * 256 + lane * 4) * 4;
-    auto stage_patch = [&](int buf, int kch) {
-        unsigned char *sb = smem + buf * WINO_PATCH + wave * 1024;
-        if (BUF) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + ii * 8192), 16, poff[ii], kch * 4, 0, 0);
-            if (wave < 2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + 16384), 16, poff[2], kch * 4, 0, 0);
-            return;
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const float *g = poff[ii] >= 0 ? sp + (poff[ii] + kch) : p.zeros;
-            GLDS16(g, sb + ii * 8192);
-        }
-        if (wave < 2) {
-            const float *g = poff[2] >= 0 ? sp + (poff[2] + kch) : p.zeros;
-            GLDS16(g, sb + 16384);
-        }
-    };
-    auto stage_u = [&](int buf, int step) {
-        unsigned char *ub = smem + WINO_UBASE + buf * 32768 + (4 * wave) * 1024;
-        if (BUF) {
-            const int us = ((n0 >> 6) * ns + step) * 32768;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(ub + i * 1024), 16, u_voff, us + i * 1024, 0, 0);
-            return;
-        }
-        const float *us = ublk + (size_t)step * 8192;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
-    };
-    auto issue_patch = [&]() {
-        stage_patch(pissued % WINO_NST, kc);
-        ++pissued;
-        kc += 8;
-        if (kc == snch && pissued < ns) {
-            kc = 0;
-            sp = p.src[1].p; snch = p.src[1].nch;
-            if (BUF) rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[1].p, 0, k.xbytes[1], 0x00020000);
-#pragma unroll
-            for (int ii = 0; ii < NPI; ++ii) { const int o = poff1[ii * 512]; poff[ii] = BUF ? (o >= 0 ? o * 4 : (int)0x80000000) : o; }
-        }
-    };
-    // wait until only the newest batch of this wave is still in flight: kind 0 = nothing issued in it, 1 = U only, 2 = patch + U
-    auto wait_landed = [&](int kind) {
-        if (kind == 0) wino_wait_vmcnt<0>();
-        else if (kind == 1) wino_wait_vmcnt<4>();
-        else if (wave < 2) wino_wait_vmcnt<7>();
-        else wino_wait_vmcnt<6>();
-    };
-
-    f32x4 acc[16][2];
-    f32x2 v0[16];
-    f32x4 bf[2][2];
-
-    // A pixels of a step -> V, column by column (B^T d on the 4 pixels of a column as they arrive, then (.) B per row
-    // in place): at most one column of raw pixels is live
-    auto load_v = [&](f32x2 (&v)[16], int buf) {
-        const unsigned char *sa = smem + buf * WINO_PATCH + offA;
-        const unsigned char *sb = smem + buf * WINO_PATCH + offB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW;
-            const f32x2 a0 = *(const f32x2 *)(src);
-            const f32x2 a1 = *(const f32x2 *)(src + 2 * WINO_ROW);
-            const f32x2 a2 = *(const f32x2 *)(src + 4 * WINO_ROW);
-            const f32x2 a3 = *(const f32x2 *)(src + 6 * WINO_ROW);
-            v[j] = pk_sub(a0, a2);
-            v[4 + j] = pk_add(a1, a2);
-            v[8 + j] = pk_sub(a2, a1);
-            v[12 + j] = pk_sub(a1, a3);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
-            v[4 * i + 0] = pk_sub(t0, t2);
-            v[4 * i + 1] = pk_add(t1, t2);
-            v[4 * i + 2] = pk_sub(t2, t1);
-            v[4 * i + 3] = pk_sub(t1, t3);
-        }
-    };
-    // MFMAs of xi combos [c0, c1) of a step (combo c = (xg = c>>1, h = c&1): 8 MFMAs), B fragments read one combo ahead;
-    // the scheduling barriers keep that order (the scheduler otherwise sinks the reads next to their use)
-    auto read_b = [&](int buf, int c) {
-        const unsigned char *sb = smem + buf * 32768 + b_rd;
-        bf[c & 1][0] = *(const f32x4 *)(sb + c * 1024);
-        bf[c & 1][1] = *(const f32x4 *)(sb + 8192 + c * 1024);
-    };
-    auto mfma_combos = [&](const f32x2 (&v)[16], int buf, int c0, int c1) {
-#pragma unroll
-        for (int c = c0; c < c1; ++c) {
-            const int xg = c >> 1, h = c & 1;
-            if (c + 1 < 8) read_b(buf, c + 1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[4 * xg + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * xg + e][h], bf[c & 1][0][e], acc[4 * xg + e][0], 0, 0, 0);
-                acc[4 * xg + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * xg + e][h], bf[c & 1][1][e], acc[4 * xg + e][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // combos 4..7 (xi 8..15) of a step with the transform of the NEXT step's V rows 0,1 (xi 0..7, whose MFMAs of this
-    // step have all issued) in their shadow: pixel reads one combo ahead of the adds that consume them.  NXT = false
-    // for the last step.  V rows 2,3 follow after the last MFMA (they are still operands until then).
-    auto mfma8 = [&](int c) {
-        const int xg = c >> 1, h = c & 1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[4 * xg + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[4 * xg + e][h], bf[c & 1][0][e], acc[4 * xg + e][0], 0, 0, 0);
-            acc[4 * xg + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[4 * xg + e][h], bf[c & 1][1][e], acc[4 * xg + e][1], 0, 0, 0);
-        }
-    };
-    auto second_half = [&](int ub, int pb, auto nxt_tag) {
-        constexpr bool NXT = decltype(nxt_tag)::value;
-        const unsigned char *sa = smem + pb * WINO_PATCH + offA;
-        const unsigned char *sb = smem + pb * WINO_PATCH + offB;
-        f32x2 r0[3], r1[3], tl[2][4];
-        auto rd = [&](int j, f32x2 (&r)[3]) {
-            const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW;
-            r[0] = *(const f32x2 *)(src);
-            r[1] = *(const f32x2 *)(src + 2 * WINO_ROW);
-            r[2] = *(const f32x2 *)(src + 4 * WINO_ROW);
-        };
-        auto col = [&](int j, const f32x2 (&r)[3]) { tl[0][j] = pk_sub(r[0], r[2]); tl[1][j] = pk_add(r[1], r[2]); };
-        read_b(ub, 5);
-        if (NXT) { rd(0, r0); rd(1, r1); }
-        mfma8(4);
-        __builtin_amdgcn_sched_barrier(0);
-        read_b(ub, 6);
-        mfma8(5);
-        if (NXT) { col(0, r0); col(1, r1); rd(2, r0); rd(3, r1); }
-        __builtin_amdgcn_sched_barrier(0);
-        read_b(ub, 7);
-        mfma8(6);
-        if (NXT) {
-            col(2, r0); col(3, r1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                v0[4 * i + 0] = pk_sub(tl[i][0], tl[i][2]);
-                v0[4 * i + 1] = pk_add(tl[i][1], tl[i][2]);
-                v0[4 * i + 2] = pk_sub(tl[i][2], tl[i][1]);
-                v0[4 * i + 3] = pk_sub(tl[i][1], tl[i][3]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(7);
-        __builtin_amdgcn_sched_barrier(0);
-        if (NXT) {
-            // V rows 2,3 from pixel rows 1,2,3
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned char *src = (j < 2 ? sa : sb) + (j & 1) * WINO_ROW + 2 * WINO_ROW;
-                const f32x2 a1 = *(const f32x2 *)(src);
-                const f32x2 a2 = *(const f32x2 *)(src + 2 * WINO_ROW);
-                const f32x2 a3 = *(const f32x2 *)(src + 4 * WINO_ROW);
-                tl[0][j] = pk_sub(a2, a1);
-                tl[1][j] = pk_sub(a1, a3);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                v0[8 + 4 * i + 0] = pk_sub(tl[i][0], tl[i][2]);
-                v0[8 + 4 * i + 1] = pk_add(tl[i][1], tl[i][2]);
-                v0[8 + 4 * i + 2] = pk_sub(tl[i][2], tl[i][1]);
-                v0[8 + 4 * i + 3] = pk_sub(tl[i][1], tl[i][3]);
-            }
-        }
-    };
-
-    // ---- main loop of one tile, one barrier per step (at its end).  Batch of step s = patches(s+3) + U(s+2), into the
-    // buffers step s-1 freed.  During step s a wave also reads and transforms the A pixels of step s+1 (landed since
-    // the previous barrier).  End of step s: everything but this step's batch has landed -> U(s+1), patches(s+2).
-    // The two waves of a SIMD (w and w+4) issue their batch half a step apart, so that one wave's LDS-DMA issue (~200
-    // cycles per instruction) hides behind the partner's MFMAs:
-    //                   early (waves 0-3): batch, 64 MFMAs, transform(s+1)
-    //                   late  (waves 4-7): 32 MFMAs, batch, 32 MFMAs, transform(s+1)
-    // Each role is its own copy of the loop (one uniform branch around the whole loop, none inside a step).
-    auto run = [&](auto role) {
-        constexpr bool EARLY = decltype(role)::value;
-        // one V array: the transform of step s+1 overwrites it once all MFMAs of step s have issued
-        auto step1 = [&](int s, auto last_tag) {
-            constexpr bool last = decltype(last_tag)::value;
-            int kind = 0;
-            const int ub = s % WINO_NST;
-            auto batch = [&]() {
-                if (DBG != 1) {
-                    if (s + 3 < ns) { issue_patch(); kind = 2; }
-                    if (s + 2 < ns) { stage_u((s + 2) % WINO_NST, s + 2); kind = kind ? kind : 1; }
-                }
-            };
-            read_b(ub, 0);
-            if (EARLY) batch();
-            mfma_combos(v0, ub, 0, 4);
-            if (!EARLY) batch();
-            __builtin_amdgcn_sched_barrier(0);
-            if (last) second_half(ub, 0, std::false_type{});
-            else second_half(ub, (s + 1) % WINO_NST, std::true_type{});
-            wait_landed(kind);
-            __builtin_amdgcn_s_barrier();
-        };
-        for (int s = 0; s + 1 < ns; ++s) step1(s, std::false_type{});
-        step1(ns - 1, std::true_type{});
-    };
-
-    // ---- epilogue of the tile (T0c, n0c), two passes (channels 32*pass..+31: the waves with wn == pass write) through a
-    // 32 KiB staging image in U buffer 2.
-    //   staging[256 rows = tile*4 + 2*py + px][32 n] floats | rowoff[256] | flags[256] (after the rings)
-    float *stg = (float *)(smem + WINO_UBASE + 2 * 32768);
-    unsigned *rowoff = (unsigned *)(smem + WINO_LDS);
-    unsigned char *rflag = smem + WINO_LDS + 1024;     // bit0: row outside the output domain, bit1: inside the deferred-ReLU window
-    auto epilogue = [&](int T0c, int n0c) {
-        if (tid < 256) {
-            const int tl2 = tid >> 2, py = (tid >> 1) & 1, px = tid & 1;
-            int T = T0c + tl2;
-            const bool tok = T < k.MT;
-            T = tok ? T : k.MT - 1;
-            const int img = fdiv(T, k.d_tpi);
-            const int rem = T - img * tpi;
-            const int ty = fdiv(rem, k.d_tx);
-            const int tx = rem - ty * k.tiles_x;
-            int oy = 2 * ty + py, ox = 2 * tx + px;
-            const bool ok = tok && oy < p.OH && ox < p.OW;
-            oy = oy < p.OH ? oy : p.OH - 1; ox = ox < p.OW ? ox : p.OW - 1;
-            unsigned off;
-            if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
-            else off = (unsigned)((img * p.OH + oy) * p.OW + ox) * (unsigned)p.DC;
-            rowoff[tid] = off;
-            const bool inwin = (p.rw1 > p.rw0) && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
-            rflag[tid] = (ok ? 0 : 1) | (inwin ? 2 : 0);
-        }
-        const bool relu_win = p.rw1 > p.rw0;
-        const int c4 = tid & 7;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            if (wn == pass) {
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
-                    const int n = nn * 16 + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float s0[4], s1[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            s0[j] = acc[j][nn][r] + acc[4 + j][nn][r] + acc[8 + j][nn][r];
-                            s1[j] = acc[4 + j][nn][r] - acc[8 + j][nn][r] - acc[12 + j][nn][r];
-                        }
-                        const int tile = wm * 16 + 4 * kg + r;
-                        float *o = stg + (tile * 4) * 32 + n;
-                        o[0] = s0[0] + s0[1] + s0[2];
-                        o[32] = s0[1] - s0[2] - s0[3];
-                        o[64] = s1[0] + s1[1] + s1[2];
-                        o[96] = s1[1] - s1[2] - s1[3];
-                    }
-                }
-            }
-            __syncthreads();
-            const int ncol = n0c + 32 * pass + 4 * c4;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = p.bias[p.cout ? n % p.cout : n]; }
-            }
-            f32x4 v[4];
-            size_t o[4];
-            unsigned char fl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = u * 64 + (tid >> 3);
-                v[u] = *(const f32x4 *)(stg + row * 32 + 4 * c4) + bv;
-                o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
-                fl[u] = rflag[row];
-            }
-            if (p.add) {
-                f32x4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.add + o[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] += t[u];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool defer = relu_win && (fl[u] & 2);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] > 0.f || defer) ? v[u][c] : 0.f;
-                }
-            }
-            if (p.mask) {
-                f32x4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.mask + o[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[u][c] = t[u][c] > 0.f ? v[u][c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (!(fl[u] & 1)) *(f32x4 *)(p.dst + o[u]) = v[u];
-            __syncthreads();           // staging (and, after pass 1, the row tables) may be rewritten
-        }
-    };
-
-    // ---- the tile
-    setup_tile(slot);
-    for (int i = 0; i < 3; ++i) issue_patch();          // ns >= 4 (every source has >= 32 channels)
-    stage_u(0, 0);
-    stage_u(1, 1);
-#pragma unroll
-    for (int x = 0; x < 16; ++x)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[x][j][r] = 0.f;
-    wino_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    load_v(v0, 0);
-    if (early) run(std::true_type{}); else run(std::false_type{});
-    epilogue(T0, n0);
-}
+// plain float2 arithmetic: the backend selects v_pk_add_f32 (inline asm here hid the VALU->MFMA hazards from the compiler)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return a - b; }
 
 // --------------------------------------------------------------------------------------------------------
-// Half-width variant: 256 threads = 64 tiles x 32 output channels, 2-deep rings (68 KiB) -> TWO workgroups per CU.
-// The workgroups of a CU are independent, so one's set-up, first-stage latency, epilogue and barrier stalls hide behind
-// the other's MFMAs, and a launch has twice as many, half as heavy workgroups (finer last round).  The price: the
-// patch image is staged once per 32 instead of per 64 output channels (34 instead of 25 LDS-DMA instructions per
-// 64x32x8 block of work).  Chosen per launch by launch_wino (short K loops and badly filled last rounds).
 constexpr int W32_UBASE = 2 * WINO_PATCH;                 // 36864
 constexpr int W32_LDS = W32_UBASE + 2 * 16384;            // 69632
 constexpr int W32_TOTAL = W32_LDS + 1280 + 5 * 256 * 4;   // + row tables + parked second-source offsets = 76032
@@ -864,12 +374,16 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
                 s0[j] = acc[j][nn][r] + acc[4 + j][nn][r] + acc[8 + j][nn][r];
                 s1[j] = acc[4 + j][nn][r] - acc[8 + j][nn][r] - acc[12 + j][nn][r];
             }
+            // staging image, bank-conflict free on both sides: pixel row u of tile t sits at row u ^ (t & 1) of the tile's
+            // four 128-B rows (neighbouring tiles of a ds_read_b128 lane group alternate bank-row halves) and channel n at
+            // n ^ 16*((t >> 2) & 1) (the two k groups of a 32-lane store group hit different banks); t & 1 = r & 1,
+            // (t >> 2) & 1 = kg & 1 here
             const int tile = wave * 16 + 4 * kg + r;
-            float *o = stg + (tile * 4) * 32 + n;
-            o[0] = s0[0] + s0[1] + s0[2];
-            o[32] = s0[1] - s0[2] - s0[3];
-            o[64] = s1[0] + s1[1] + s1[2];
-            o[96] = s1[1] - s1[2] - s1[3];
+            float *o = stg + tile * 128 + (n ^ ((kg & 1) << 4));
+            o[((0 ^ (r & 1))) * 32] = s0[0] + s0[1] + s0[2];
+            o[((1 ^ (r & 1))) * 32] = s0[1] - s0[2] - s0[3];
+            o[((2 ^ (r & 1))) * 32] = s1[0] + s1[1] + s1[2];
+            o[((3 ^ (r & 1))) * 32] = s1[1] - s1[2] - s1[3];
         }
     }
     __syncthreads();
@@ -888,8 +402,9 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         unsigned char fl[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int row = ((it >> 2) * 32 + (tid >> 3)) * 4 + u;        // the four pixels of one tile
-            v[u] = *(const f32x4 *)(stg + row * 32 + 4 * c4) + bv;
+            const int tloc = (it >> 2) * 32 + (tid >> 3);
+            const int row = tloc * 4 + u;                                  // the four pixels of one tile
+            v[u] = *(const f32x4 *)(stg + tloc * 128 + (u ^ (tloc & 1)) * 32 + ((4 * c4) ^ (((tloc >> 2) & 1) << 4))) + bv;
             o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
             fl[u] = rflag[row];
         }
@@ -934,7 +449,6 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     }
 }
 
-double igemm_alg_flops(const IgemmP &p);
 
 bool wino_applicable(const IgemmP &p)
 {
@@ -948,22 +462,16 @@ bool wino_applicable(const IgemmP &p)
 
 size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * Nn; }
 
-// true iff launch_igemm will hand this 3x3 launch to the half-width Winograd kernel, whose epilogue can also write the 2x2
+// true iff launch_igemm will hand this 3x3 launch to the Winograd kernel with an epilogue that can also write the 2x2
 // max-pool of its output (IgemmP::pool_dst)
 bool wino_fuses_pool(const IgemmP &p)
 {
-    if (get_math_mode() != 3 || !wino_applicable(p) || p.scatter || (p.OH & 1) || (p.OW & 1) || p.dn0 || p.DC != p.Nn) return false;
-    const char *e32 = getenv("UNET_WINO32");
-    if (e32 && atoi(e32) == 0) return false;
-    const char *ed = getenv("UNET_WINO_DBG");
-    return !(ed && atoi(ed) == 1);
+    return p.math == 3 && wino_applicable(p) && !p.scatter && !(p.OH & 1) && !(p.OW & 1) && !p.dn0 && p.DC == p.Nn;
 }
 
 // p must have passed launch_igemm's argument checks (launch_igemm calls this)
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
 {
-    static const int dbg = [] { const char *e = getenv("UNET_WINO_DBG"); return e ? atoi(e) : 0; }();
-    constexpr int LDS = WINO_LDS + 1280 + 3 * 512 * 4;          // rings + the epilogue's row tables + parked second-source offsets
     WinoP q;
     q.p = p;
     q.U = U;
@@ -976,16 +484,10 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     q.d_tpi = make_fastdiv((unsigned)(q.tiles_x * q.tiles_y));
     q.d_tx = make_fastdiv((unsigned)q.tiles_x);
     q.p.mtiles = cdiv(q.MT, 64);
-    q.p.ntiles = p.Nn / 64;
-    // variant: 0 = 512 threads x (64 tiles x 64 n), 1 = 256 threads x (64 tiles x 32 n), two per CU (UNET_WINO32: -1 auto)
-    // Measured over the net's 42 launches: with buffer-descriptor DMA the half-width variant is the faster or
-    // equal one for every launch (19.37 vs 19.87 ms per step), so it is the default; UNET_WINO32=0 selects the 64-wide
-    // kernel (read per launch: the tests exercise both).
-    const char *e32 = getenv("UNET_WINO32");
-    const bool half = e32 ? atoi(e32) != 0 : true;
-    // buffer-descriptor LDS-DMA needs every tensor below 2 GiB (32-bit num_records and the out-of-range marker)
-    static const int usebuf = [] { const char *e = getenv("UNET_WINO_BUF"); return e ? atoi(e) : 1; }();
-    bool buf = usebuf != 0;
+    q.p.ntiles = p.Nn / 32;
+    // buffer-descriptor LDS-DMA needs every tensor below 2 GiB (32-bit num_records and the out-of-range marker);
+    // larger tensors (config #5 at batch 16) and unet_set_lds_dma(0) take the global_load_lds instantiation
+    bool buf = get_lds_dma_mode() != 0;
     {
         const size_t ub = wino_u_floats(kc, p.Nn) * sizeof(float);
         if (ub >= 0x7FFFFFFFull) buf = false;
@@ -999,28 +501,13 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
             }
         }
     }
-    if (half && dbg != 1) {
-        static bool attr32[64] = {false}, attr32b[64] = {false};
-        auto k32 = buf ? wino32_f32_kernel<true> : wino32_f32_kernel<false>;
-        if (int rc_ = ensure_dynamic_lds((const void *)k32, W32_TOTAL, buf ? attr32b : attr32)) return rc_;
-        q.p.ntiles = p.Nn / 32;
-        char tag32[96];
-        snprintf(tag32, sizeof(tag32), "wino32 M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
-        prof_begin(3, igemm_alg_flops(p), st, tag32);
-        hipLaunchKernelGGL(k32, dim3(q.p.mtiles * q.p.ntiles), dim3(256), W32_TOTAL, st, q);
-        prof_end(st);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    auto kern = dbg == 1 ? wino_f32_kernel<1, false> : buf ? wino_f32_kernel<0, true> : wino_f32_kernel<0, false>;
-    static bool attr_done[64] = {false}, attr_done1[64] = {false}, attr_doneb[64] = {false};
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, dbg == 1 ? attr_done1 : buf ? attr_doneb : attr_done)) return rc_;
-    const int total = q.p.mtiles * q.p.ntiles;
-    const int grid = total;
-    char tag[96];
-    snprintf(tag, sizeof(tag), "wino M=%d N=%d Kd=%d nsrc=%d tiles=%d", p.M, p.Nn, p.Kd, p.nsrc, q.MT);
-    prof_begin(3, igemm_alg_flops(p), st, tag);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, q);
+    static bool attr32[64] = {false}, attr32b[64] = {false};
+    auto k32 = buf ? wino32_f32_kernel<true> : wino32_f32_kernel<false>;
+    if (int rc_ = ensure_dynamic_lds((const void *)k32, W32_TOTAL, buf ? attr32b : attr32)) return rc_;
+    char tag32[96];
+    snprintf(tag32, sizeof(tag32), "wino32<%d> M=%d N=%d Kd=%d nsrc=%d tiles=%d", (int)buf, p.M, p.Nn, p.Kd, p.nsrc, q.MT);
+    prof_begin(PK_WINO, tag32, st, igemm_alg_flops(p), igemm_alg_flops(p) * (16.0 / 36.0), igemm_alg_bytes(p));
+    hipLaunchKernelGGL(k32, dim3(q.p.mtiles * q.p.ntiles), dim3(256), W32_TOTAL, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;

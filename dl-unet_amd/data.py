@@ -31,13 +31,12 @@ def mirror_transform(image, normalise=False):
         raise ValueError("mirror_transform expects square images")
     B, n, _ = x.shape
     _, S, _ = input_size_compute(x)
-    L = _hip.lib()
     mm = None
     if normalise:
         mm = torch.empty(B, 2, dtype=torch.float32, device=x.device)
-        _hip.check(L.unet_minmax(_hip.ptr(x), B, n * n, _hip.ptr(mm), _hip.stream()), "unet_minmax")
+        _hip.run("unet_minmax", x.device, _hip.ptr(x), B, n * n, _hip.ptr(mm))
     out = torch.empty(B, 1, S, S, dtype=torch.float32, device=x.device)
-    _hip.check(L.unet_mirror_pad(_hip.ptr(x), B, n, S, _hip.ptr(mm), _hip.ptr(out), _hip.stream()), "unet_mirror_pad")
+    _hip.run("unet_mirror_pad", x.device, _hip.ptr(x), B, n, S, _hip.ptr(mm), _hip.ptr(out))
     return out[0, 0] if single else out
 
 
@@ -76,18 +75,17 @@ def elastic_transform(images, alpha, sigma, random_state=None, fields=None):
         f1 = torch.from_numpy(np.stack([d[1] for d in draws])).float().to(dev)
     else:
         f0 = torch.rand(B, H, W, device=dev); f1 = torch.rand(B, H, W, device=dev)
-    L = _hip.lib()
     w, radius = gaussian_taps(sigma)
     wd = torch.from_numpy(w).to(dev)
     tmp = torch.empty_like(f0)
     dx = torch.empty_like(f0); dy = torch.empty_like(f0)
     # dx displaces rows (axis 0), dy columns (axis 1) — the reference's naming (data.py:238-243)
-    _hip.check(L.unet_gaussian_filter(_hip.ptr((f0 * 2 - 1).contiguous()), B, H, W, _hip.ptr(wd), radius, float(alpha), _hip.ptr(tmp), _hip.ptr(dx), _hip.stream()))
-    _hip.check(L.unet_gaussian_filter(_hip.ptr((f1 * 2 - 1).contiguous()), B, H, W, _hip.ptr(wd), radius, float(alpha), _hip.ptr(tmp), _hip.ptr(dy), _hip.stream()))
+    _hip.run("unet_gaussian_filter", dev, _hip.ptr((f0 * 2 - 1).contiguous()), B, H, W, _hip.ptr(wd), radius, float(alpha), _hip.ptr(tmp), _hip.ptr(dx))
+    _hip.run("unet_gaussian_filter", dev, _hip.ptr((f1 * 2 - 1).contiguous()), B, H, W, _hip.ptr(wd), radius, float(alpha), _hip.ptr(tmp), _hip.ptr(dy))
     outs = []
     for im in images:
         x = _as_batch(im).contiguous().float()
         o = torch.empty_like(x)
-        _hip.check(L.unet_warp_bilinear(_hip.ptr(x), _hip.ptr(dx), _hip.ptr(dy), B, H, W, _hip.ptr(o), _hip.stream()))
+        _hip.run("unet_warp_bilinear", dev, _hip.ptr(x), _hip.ptr(dx), _hip.ptr(dy), B, H, W, _hip.ptr(o))
         outs.append(o.reshape(im.shape))
     return outs

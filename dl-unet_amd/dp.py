@@ -2,13 +2,18 @@
 backward), one process per GPU, and ONE exchange step — the gradient all-reduce.
 
 The backward is cut into stages in reverse layer order (unet_backward_stage); all parameters a stage
-completes are contiguous in one flat fp32 buffer, so each stage is one bucket handed to RCCL
-(`torch.distributed` backend "nccl") as soon as its kernels are enqueued, overlapping the remaining
-stages.  Gradients are linear in dlogits, so the caller pre-scales dlogits by 1/world and the buckets
-are SUM-reduced: the result equals the single-process gradient of the global-batch mean loss.
+completes are contiguous in one flat fp32 buffer, so each stage is one bucket handed to RCCL — the
+library's own communicator and stream, unet_dp_allreduce (csrc/dp.hip) — as soon as its kernels are
+enqueued, overlapping the remaining stages.  Gradients are linear in dlogits, so the caller pre-scales
+dlogits by 1/world and the buckets are SUM-reduced: the result equals the single-process gradient of
+the global-batch mean loss.
 
-Nothing here touches HIP directly, so the bucket logic is testable with gloo on CPU.
+GradBuckets touches neither HIP nor RCCL, so the bucket logic is testable with gloo on CPU; the
+DataParallel object's "torch" backend keeps that path usable on a GPU box with one GPU (two gloo ranks
+sharing it), its "rccl" backend is what bench.py and training use.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -50,6 +55,71 @@ class GradBuckets:
         """Asynchronous SUM all-reduce of stage s's bucket; returns the work handle."""
         a, b = self.bucket_range(s)
         return dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+class DataParallel:
+    """Rank/world bookkeeping + the collective calls of one module replica."""
+
+    def __init__(self, handle, device, group=None, backend="rccl"):
+        if backend not in ("rccl", "torch"):
+            raise ValueError("backend must be 'rccl' or 'torch'")
+        self.group, self.backend, self.device = group, backend, device
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
+        self._works = []
+        if backend == "torch":
+            if not inited:
+                raise RuntimeError("backend 'torch' needs torch.distributed.init_process_group first")
+            return
+        import _hip
+        L = _hip.lib()
+        # rendezvous: rank 0 makes the id, torch.distributed (any backend) carries the 128 bytes
+        idbuf = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _hip.check(L.unet_dp_unique_id(idbuf), "unet_dp_unique_id")
+        if self.world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=device if on_gpu else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = (C.c_ubyte * 128)(*t.cpu().tolist())
+        with torch.cuda.device(device):
+            _hip.check(L.unet_dp_init(handle.h, self.rank, self.world, idbuf), "unet_dp_init")
+        self._handle = handle
+
+    def broadcast_parameters(self, params):
+        if self.world <= 1 and self.backend == "torch":
+            return
+        with torch.no_grad(), torch.cuda.device(self.device):
+            if self.backend == "torch":
+                for p in params:
+                    dist.broadcast(p, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                return
+            import _hip
+            L = _hip.lib()
+            st = _hip.stream(self.device)
+            for p in params:
+                _hip.check(L.unet_dp_broadcast(self._handle.h, _hip.ptr(p), p.numel(), 0, st), "unet_dp_broadcast")
+            _hip.check(L.unet_dp_join(self._handle.h, st), "unet_dp_join")
+
+    def reduce_stage(self, buckets, flat, s, handle, stream):
+        """SUM all-reduce of backward stage s's bucket, asynchronous with respect to `stream`."""
+        if self.backend == "torch":
+            self._works.append(buckets.reduce_stage(flat, s, self.group))
+            return
+        import _hip
+        a, b = buckets.bucket_range(s)
+        _hip.check(_hip.lib().unet_dp_allreduce(handle.h, C.c_void_p(flat.data_ptr() + 4 * a), b - a, stream), "unet_dp_allreduce")
+
+    def join(self, handle, stream):
+        """After this, work enqueued on `stream` sees the reduced gradients."""
+        if self.backend == "torch":
+            for w in self._works:
+                w.wait()
+            self._works = []
+            return
+        import _hip
+        _hip.check(_hip.lib().unet_dp_join(handle.h, stream), "unet_dp_join")
 
 
 def world_size(group=None):

@@ -27,7 +27,7 @@ def class_balance(gt_batch):
         B, H, W = gt.shape
         w = torch.empty(B, H, W, dtype=torch.float32, device=gt.device)
         counts = torch.empty(B, dtype=torch.int64, device=gt.device)
-        _hip.check(_hip.lib().unet_class_balance(_hip.ptr(gt), B, H, W, _hip.ptr(w), _hip.ptr(counts), _hip.stream()), "unet_class_balance")
+        _hip.run("unet_class_balance", gt.device, _hip.ptr(gt), B, H, W, _hip.ptr(w), _hip.ptr(counts))
         if bool(((counts == 0) | (counts == H * W)).any()):      # the reference indexes counts[1]: a one-class image raises
             raise IndexError("index 1 is out of bounds for dimension 0 with size 1")
         return w

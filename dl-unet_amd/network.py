@@ -4,7 +4,8 @@ Same class, constructor (no arguments), submodule names, 46 state-dict keys/shap
 surface as the reference (network.py:8-192), but `forward` runs the hand-written HIP path for gfx950
 through the C ABI of libunet_hip.so (include/unet_hip.h) and backward is the library's own
 dgrad/wgrad kernels behind one torch.autograd.Function.  PyTorch supplies parameter storage,
-device memory, streams and (for data parallel) torch.distributed — nothing on the compute path.
+device memory and streams; for data parallel the gradient all-reduce is the library's RCCL call
+(unet_dp_*), torch.distributed only carries the 128-byte rendezvous id between the ranks.
 
 There is no CPU fallback: calling the module with a host tensor raises.
 """
@@ -86,13 +87,14 @@ class _UnetFunction(torch.autograd.Function):
         dev = x.device.index
         h = _handle(dev, module.base_ch)
         B, _, S, _ = x.shape
-        nbytes = h.workspace_bytes(B, S, True)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         So = S - 184
-        logits = torch.empty(B, 2, So, So, dtype=torch.float32, device=x.device)
-        ptab = _hip.ptr_table(params)
-        _hip.check(_hip.lib().unet_forward(h.h, ptab, _hip.ptr(x), _hip.ptr(logits), B, S, _hip.ptr(ws), nbytes, 1,
-                                           _hip.stream()), "unet_forward")
+        with torch.cuda.device(x.device):               # the library checks that the handle's device is current
+            nbytes = h.workspace_bytes(B, S, True)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            logits = torch.empty(B, 2, So, So, dtype=torch.float32, device=x.device)
+            ptab = _hip.ptr_table(params)
+            _hip.check(_hip.lib().unet_forward(h.h, ptab, _hip.ptr(x), _hip.ptr(logits), B, S, _hip.ptr(ws), nbytes, 1,
+                                               _hip.stream(x.device)), "unet_forward")
         ctx.save_for_backward(*params)
         ctx.ws, ctx.nbytes, ctx.dev, ctx.module = ws, nbytes, dev, module
         return logits
@@ -104,21 +106,22 @@ class _UnetFunction(torch.autograd.Function):
         h = _handle(ctx.dev, module.base_ch)
         L = _hip.lib()
         buckets = module._buckets
-        flat, grads = buckets.allocate([p.shape for p in params], dlogits.device)
         dp = module._dp
-        dlogits = dlogits.contiguous()
-        if dp is not None and dp[1] > 1:
-            dlogits = dlogits * (1.0 / dp[1])              # grads are linear in dlogits: SUM-reduce == mean
-        ptab, gtab = _hip.ptr_table(params), _hip.ptr_table(grads)
-        works = []
-        for s in range(buckets.n_stages()):
-            _hip.check(L.unet_backward_stage(h.h, s, ptab, _hip.ptr(dlogits), gtab, _hip.ptr(ctx.ws), ctx.nbytes,
-                                             _hip.stream()), "unet_backward_stage %d" % s)
+        with torch.cuda.device(dlogits.device):
+            flat, grads = buckets.allocate([p.shape for p in params], dlogits.device)
+            dlogits = dlogits.contiguous()
+            if dp is not None and dp.world > 1:
+                dlogits = dlogits * (1.0 / dp.world)           # grads are linear in dlogits: SUM-reduce == mean
+            ptab, gtab = _hip.ptr_table(params), _hip.ptr_table(grads)
+            st = _hip.stream(dlogits.device)
+            for s in range(buckets.n_stages()):
+                _hip.check(L.unet_backward_stage(h.h, s, ptab, _hip.ptr(dlogits), gtab, _hip.ptr(ctx.ws), ctx.nbytes, st),
+                           "unet_backward_stage %d" % s)
+                if dp is not None:
+                    # all-reduce of this stage's bucket on the communicator's stream, overlapping the next stage
+                    dp.reduce_stage(buckets, flat, s, h, st)
             if dp is not None:
-                # RCCL all-reduce of this bucket on the communicator's stream, overlapping the next stage
-                works.append(buckets.reduce_stage(flat, s, dp[0]))
-        for w in works:
-            w.wait()
+                dp.join(h, st)
         ctx.ws = None
         return (None, None) + tuple(grads)
 
@@ -149,15 +152,17 @@ class Unet(nn.Module):
         self._buckets = None
 
     # -- data parallel: batch-sharded replicas, gradients averaged with RCCL over xGMI -------------
-    def enable_data_parallel(self, process_group=None):
-        import torch.distributed as dist
-        world = dist.get_world_size(process_group)
-        self._dp = (process_group, world)
-        if world > 1:
-            with torch.no_grad():
-                for p in self.parameters():
-                    dist.broadcast(p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
-                                   group=process_group)
+    def enable_data_parallel(self, process_group=None, backend="rccl"):
+        """Batch-sharded data parallel, one process per GPU.  backend "rccl": the library's own RCCL
+        communicator (unet_dp_*; torch.distributed, if initialised, only carries the rendezvous id — without it a
+        one-rank communicator is made); backend "torch": torch.distributed.all_reduce on the given group (what the
+        CPU/gloo tests use).  Parameters are broadcast from rank 0."""
+        params = self._params()
+        if not all(p.is_cuda for p in params):
+            raise RuntimeError("enable_data_parallel: move the module to its HIP device first (.to('cuda:N'))")
+        dev = params[0].device
+        self._dp = dp_mod.DataParallel(_handle(dev.index, self.base_ch), dev, process_group, backend)
+        self._dp.broadcast_parameters(params)
         return self
 
     def _params(self):
@@ -197,9 +202,10 @@ class Unet(nn.Module):
         # inference (trainer.py:95 no_grad): no activation-gradient storage
         h = _handle(t.device.index, self.base_ch)
         B, _, S, _ = t.shape
-        nbytes = h.workspace_bytes(B, S, False)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
-        logits = torch.empty(B, 2, S - 184, S - 184, dtype=torch.float32, device=t.device)
-        _hip.check(_hip.lib().unet_forward(h.h, _hip.ptr_table([p.detach() for p in params]), _hip.ptr(t), _hip.ptr(logits),
-                                           B, S, _hip.ptr(ws), nbytes, 0, _hip.stream()), "unet_forward")
+        with torch.cuda.device(t.device):
+            nbytes = h.workspace_bytes(B, S, False)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+            logits = torch.empty(B, 2, S - 184, S - 184, dtype=torch.float32, device=t.device)
+            _hip.check(_hip.lib().unet_forward(h.h, _hip.ptr_table([p.detach() for p in params]), _hip.ptr(t), _hip.ptr(logits),
+                                               B, S, _hip.ptr(ws), nbytes, 0, _hip.stream(t.device)), "unet_forward")
         return logits

@@ -22,9 +22,8 @@ class _BCEFn(torch.autograd.Function):
         dl = torch.empty_like(logits)
         sc = torch.empty(_hip.lib().unet_bce_scratch_bytes(logits.numel()), dtype=torch.uint8, device=logits.device)
         ws = wstrides if weight is not None else (0, 0, 0, 0)
-        _hip.check(_hip.lib().unet_bce_logits(_hip.ptr(logits), _hip.ptr(target), _hip.ptr(weight), ws[0], ws[1], ws[2], ws[3],
-                                              B, H, W, _hip.ptr(loss), _hip.ptr(dl), float(grad_scale), _hip.ptr(sc), _hip.stream()),
-                   "unet_bce_logits")
+        _hip.run("unet_bce_logits", logits.device, _hip.ptr(logits), _hip.ptr(target), _hip.ptr(weight), ws[0], ws[1], ws[2], ws[3],
+                 B, H, W, _hip.ptr(loss), _hip.ptr(dl), float(grad_scale), _hip.ptr(sc))
         ctx.save_for_backward(dl)
         return loss
 
@@ -60,7 +59,7 @@ def onehot2(labels, like):
     labels = labels.to(like.device).contiguous()
     B, _, H, W = like.shape
     out = torch.empty(B, 2, H, W, dtype=torch.float32, device=like.device)
-    _hip.check(_hip.lib().unet_onehot2(_hip.ptr(labels), _hip.ptr(out), B, H, W, _hip.stream()), "unet_onehot2")
+    _hip.run("unet_onehot2", like.device, _hip.ptr(labels), _hip.ptr(out), B, H, W)
     return out
 
 
@@ -69,8 +68,7 @@ def argmax2(preds):
     B, two, H, W = preds.shape
     assert two == 2 and preds.stride(3) == 1
     out = torch.empty(B, H, W, dtype=torch.int64, device=preds.device)
-    _hip.check(_hip.lib().unet_argmax2(_hip.ptr(preds), preds.stride(0), preds.stride(1), preds.stride(2), _hip.ptr(out),
-                                       B, H, W, _hip.stream()), "unet_argmax2")
+    _hip.run("unet_argmax2", preds.device, _hip.ptr(preds), preds.stride(0), preds.stride(1), preds.stride(2), _hip.ptr(out), B, H, W)
     return out
 
 
@@ -97,9 +95,8 @@ class SGD(torch.optim.Optimizer):
                     bufs = [self.state[p]["momentum_buffer"] for p in chunk]
                     grads = [p.grad.contiguous() for p in chunk]
                     numel = (C.c_size_t * len(chunk))(*[p.numel() for p in chunk])
-                    _hip.check(_hip.lib().unet_sgd_momentum(_hip.ptr_table(chunk), _hip.ptr_table(grads), _hip.ptr_table(bufs),
-                                                            numel, len(chunk), float(group["lr"]), float(group["momentum"]),
-                                                            is_first, _hip.stream()), "unet_sgd_momentum")
+                    _hip.run("unet_sgd_momentum", chunk[0].device, _hip.ptr_table(chunk), _hip.ptr_table(grads), _hip.ptr_table(bufs),
+                             numel, len(chunk), float(group["lr"]), float(group["momentum"]), is_first)
 
 
 def crop_argmax_metrics(preds, labels=None):
@@ -116,6 +113,6 @@ def crop_argmax_metrics(preds, labels=None):
     pad = int((So - n) / 2)
     mask = torch.empty(B, n, n, dtype=torch.int64, device=preds.device)
     stats = torch.empty(B, 3, dtype=torch.int64, device=preds.device) if labels is not None else None
-    _hip.check(_hip.lib().unet_eval_masks(_hip.ptr(preds), preds.stride(0), preds.stride(1), preds.stride(2), pad, _hip.ptr(labels),
-                                          _hip.ptr(mask), B, n, _hip.ptr(stats), _hip.stream()), "unet_eval_masks")
+    _hip.run("unet_eval_masks", preds.device, _hip.ptr(preds), preds.stride(0), preds.stride(1), preds.stride(2), pad, _hip.ptr(labels),
+             _hip.ptr(mask), B, n, _hip.ptr(stats))
     return mask, stats

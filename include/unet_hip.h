@@ -14,7 +14,9 @@
  *     OIHW, transposed-conv weights IOHW, int64 labels/masks.  Internally activations are
  *     NHWC fp32 (per-op entry points take NHWC).
  *   - The caller owns every buffer, including the workspace (size: unet_workspace_bytes).
- *   - All work is enqueued on the caller's stream; a handle is re-entrant per stream.
+ *   - All work is enqueued on the caller's stream; a handle is re-entrant per stream: nothing a call needs lives in
+ *     process-wide state (the arithmetic mode is fixed per forward and kept with its plan for the backward).
+ *   - One process per GPU: a handle's calls must be made while its device is the current HIP device (checked).
  */
 #ifndef UNET_HIP_H
 #define UNET_HIP_H
@@ -33,7 +35,8 @@ enum {
     UNET_E_BADSIZE  = -1,         /* S must be 16L+60 with L even >= 8 (network.py:124-127, Q7) */
     UNET_E_BADARG   = -2,
     UNET_E_NOTREADY = -3,         /* backward without a training forward on this workspace */
-    UNET_E_UNSUPPORTED = -4
+    UNET_E_UNSUPPORTED = -4,
+    UNET_E_COMM     = -5          /* RCCL error (data parallel) */
 };
 
 typedef struct unet_handle unet_handle;
@@ -41,12 +44,14 @@ typedef struct unet_handle unet_handle;
 typedef struct unet_config {
     int base_ch;                  /* 64 in the reference (network.py:23); 32 for config #5 */
     int device;                   /* HIP device ordinal */
+    int math;                     /* arithmetic of this handle's forwards/backwards (codes below); -1 = follow unet_set_math */
 } unet_config;
 
 const char *unet_last_error(void);
 int unet_abi_version(void);
 
-/* Arithmetic of the dense contractions (process-wide):
+/* Arithmetic of the dense contractions — the process default, used by the per-op entry points and by handles created
+ * with math = -1 (read when a forward is planned; its backward keeps that forward's mode):
  * 3 = fp32 on the fp32 MFMA, the stride-1 3x3 layers' forward and dgrad as Winograd F(2x2,3x3) (default: 16 of the 36
  *     multiplies of the direct correlation, all arithmetic fp32, same parity tolerances as mode 0),
  * 0 = fp32 on the fp32 MFMA, direct correlation everywhere (fmaf-chain numerics),
@@ -55,6 +60,10 @@ int unet_abi_version(void);
  *     (BASELINE config #3).  Tensors in HBM stay fp32 in every mode.  Also settable with UNET_MATH.           */
 int unet_set_math(int mode);
 int unet_get_math(void);
+/* Operand staging of the MFMA kernels: 1 (default) = LDS-DMA through buffer descriptors whenever every tensor of a launch is
+ * below 2 GiB, else global_load_lds; 0 = always global_load_lds (what tensors >= 2 GiB take, e.g. config #5 at batch 16).
+ * A tuning / test knob: results are identical.  Also settable with UNET_LDS_DMA.                                       */
+int unet_set_lds_dma(int mode);
 
 /* ---- handle ------------------------------------------------------------------------------
  * replaces: Unet.__init__ bookkeeping that is not parameters (network.py:20-58).            */
@@ -105,17 +114,39 @@ double unet_flops(const unet_handle *h, int B, int S, int backward);
 int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const char *name,
                       size_t *offset, int *extent, int *channels);
 
+/* ---- data parallel (the reference is single-device, main_main.py:157-158) -------------------------
+ * Batch-sharded replicas, one process per GPU; the only exchange is the gradient all-reduce, done by RCCL over xGMI on
+ * a communicator stream owned by the handle.  Rendezvous: rank 0 calls unet_dp_unique_id and the HOST carries the
+ * UNET_DP_ID_BYTES to every rank (any channel), then every rank calls unet_dp_init.
+ *   unet_dp_allreduce : in-place SUM all-reduce of `count` fp32 at `buf`, ordered after everything enqueued on `stream`
+ *                       so far, running on the communicator stream (the caller's stream is not blocked: issue it after
+ *                       each unet_backward_stage to overlap the bucket with the next stage)
+ *   unet_dp_join      : `stream` waits for every collective issued so far (call before the optimizer step)
+ *   unet_dp_broadcast : `count` fp32 from `root` to all ranks (initial parameters); same ordering as allreduce
+ * Gradients are linear in dlogits: scale dlogits by 1/world (unet_bce_logits grad_scale) and SUM == global-batch mean. */
+#define UNET_DP_ID_BYTES 128
+int unet_dp_unique_id(void *id_out_host);
+int unet_dp_init(unet_handle *h, int rank, int world, const void *id_host);
+int unet_dp_destroy(unet_handle *h);
+int unet_dp_world(unet_handle *h);                /* ranks of the handle's communicator, 0 if none */
+int unet_dp_rccl_version(void);                   /* ncclGetVersion of the bound librccl, 0 if it cannot be loaded */
+int unet_dp_allreduce(unet_handle *h, void *buf, size_t count, void *stream);
+int unet_dp_broadcast(unet_handle *h, void *buf, size_t count, int root, void *stream);
+int unet_dp_join(unet_handle *h, void *stream);
+
 /* ---- measurement -----------------------------------------------------------------------------
- * Optional HIP-event timing around every launch of a kernel family, recorded on the launch
- * stream (bench.py's roofline.achieved is measured with this inside its timed region).
- * family: 0 = implicit-GEMM (conv fwd / dgrad / up-conv), 1 = weight-gradient, 2 = its reduce.
- * Families: 0 implicit GEMM (igemm*.hip), 1 weight gradient, 2 its split-K reduce, 3 Winograd 3x3 (wino.hip).
- * unet_profile_read synchronises on the recorded events and returns totals since the last reset:
- * elapsed ms, launch count and the algorithmic FLOPs (2*MAC, in-bounds taps only) of the launches. */
+ * Optional HIP-event timing around every kernel launch, recorded on the launch stream (bench.py's roofline block and
+ * per-layer table are measured with this inside its timed region).  Every launch records its kernel kind, the SURVEY 8a
+ * row it belongs to, its algorithmic FLOPs (2*MAC, in-bounds taps only), the FLOPs the matrix cores execute for it
+ * (Winograd: 16/36 of the direct count; tile padding included) and its algorithmic HBM bytes.
+ * kind: 0 implicit GEMM (igemm*.hip), 1 weight gradient, 2 its split-K reduce, 3 Winograd 3x3 (wino.hip),
+ *       4 conv11c stencil, 5 element-wise / reductions (pool, head, loss, SGD, packers), 6 RCCL collectives.
+ * unet_profile_read synchronises on the recorded events and returns totals of one kind since the last reset.       */
 int unet_profile_enable(int on);
 int unet_profile_reset(void);
-int unet_profile_read(int family, double *ms_total, long *launches, double *flops_total);
-/* one CSV line per recorded launch: family,ms,gflop,tag (shape of the launch) */
+int unet_profile_read(int kind, double *ms_total, long *launches, double *flops_total, double *exec_flops_total,
+                      double *bytes_total);
+/* one CSV line per recorded launch: kind,ms,gflop,exec_gflop,mbytes,row,tag */
 int unet_profile_dump(const char *path);
 
 /* ---- step-side kernels (L1-L3) -------------------------------------------------------------

@@ -77,4 +77,44 @@ def check_same_branch(S, B, seed_w=0, seed_x=1, seed_dl=2, dlogits=None):
     ref_logits, ref_grads = oracle_c.unet_fwd_bwd(p64, x.astype(np.float64), dlogits=np.asarray(dl, dtype=np.float64),
                                                   relu_masks=masks, pool_sel=sels)
     return {"fwd": nerr(logits, ref_logits), "grads": {k: nerr(grads[k], ref_grads[k]) for k in grads},
-            "logits": logits, "hip_grads": grads}
+            "logits": logits, "hip_grads": grads, "ref_grads": ref_grads, "masks": masks, "sels": sels}
+
+
+# layer whose ReLU output each entry of RELU_BUFS is (network.py:131-188)
+RELU_LAYER = {"a1_%d" % l: "conv%d1c" % (l + 1) for l in range(5)}
+RELU_LAYER.update({"a2_%d" % l: "conv%d2c" % (l + 1) for l in range(5)})
+RELU_LAYER.update({"d1_%d" % l: "conv%d1e" % (l + 1) for l in range(4)})
+RELU_LAYER.update({"d2_%d" % l: "conv%d2e" % (l + 1) for l in range(4)})
+
+
+def branch_disagreements(masks, sels, S, B, seed_w=0, seed_x=1):
+    """Where does the HIP forward's piecewise-linear branch differ from the fp64 forward's, and by how much did the
+    fp64 value miss the decision boundary there?  Returns (n_relu, n_pool, worst): worst = the largest fp64 margin of
+    a disagreeing element, normalised by its layer's scale (|z|max): a legitimate fp32 evaluation only ever disagrees
+    where that margin is at the level of the forward rounding error."""
+    import torch
+    from . import torch_ref
+    p = torch_ref.params_to_torch(prng.make_params(seed_w), torch.float64)
+    x = torch.from_numpy(prng.make_input(seed_x, B, S)).double()
+    pre = {}
+    torch_ref.unet_forward(p, x, pre=pre)
+    n_relu = n_pool = 0
+    worst = 0.0
+    for name, m in zip(RELU_BUFS, masks):
+        z = pre[RELU_LAYER[name]].numpy()
+        diff = (z > 0) != (m > 0)
+        n_relu += int(diff.sum())
+        if diff.any():
+            worst = max(worst, float(np.abs(z[diff]).max() / np.abs(z).max()))
+    for l, sel in enumerate(sels):
+        a = np.maximum(pre["conv%d2c" % (l + 1)].numpy(), 0.0)                       # pooled tensor = ReLU output
+        Bq, Cc, H, W = a.shape
+        win = a.reshape(Bq, Cc, H // 2, 2, W // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(Bq, Cc, H // 2, W // 2, 4)
+        ref = win.argmax(axis=-1)                                                    # first maximum on ties
+        diff = ref != sel
+        n_pool += int(diff.sum())
+        if diff.any():
+            chosen = np.take_along_axis(win, sel[..., None].astype(np.int64), axis=-1)[..., 0]
+            gap = (win.max(axis=-1) - chosen)[diff]
+            worst = max(worst, float(gap.max() / max(np.abs(a).max(), 1e-300)))
+    return n_relu, n_pool, worst

@@ -16,9 +16,13 @@ def crop_and_concat(A, B):
     return torch.cat((F.pad(A, (-c, -c, -c, -c)), B), 1)
 
 
-def unet_forward(p, t):
+def unet_forward(p, t, pre=None):
+    """pre: optional dict that receives every ReLU'd conv's PRE-activation by layer name (branch analysis in the tests)."""
     def cr(name, t):
-        return F.relu(F.conv2d(t, p[name + ".weight"], p[name + ".bias"]))
+        z = F.conv2d(t, p[name + ".weight"], p[name + ".bias"])
+        if pre is not None:
+            pre[name] = z.detach()
+        return F.relu(z)
 
     def up(name, t):
         return F.conv_transpose2d(t, p[name + ".weight"], p[name + ".bias"], stride=2)

@@ -110,3 +110,35 @@ def test_config5_overlap_tile_inference_base32(dev):
     assert ((y.cpu() - yr).abs().max() / yr.abs().max()).item() < 2e-5
     with pytest.raises(RuntimeError):                # training needs base_ch % 64 == 0 (weight-gradient tiles)
         net(x).sum().backward()
+
+
+def test_config5_at_its_real_batch_crosses_2GiB(dev):
+    """BASELINE configs[4] as stated: batch 16 of 1024^2 images -> 1212^2 inputs, 32-base-ch net, crop/argmax/pixel error.
+    The first activation is 16 x 1210^2 x 32 x 4 B = 3.0 GB: above 2 GiB the MFMA kernels stage with global_load_lds
+    instead of buffer descriptors (32-bit num_records).  Every tile of the batch must equal the same image run alone
+    (the B=1 path is oracle-checked in the test above)."""
+    import data
+    import network
+    import optim as hip_optim
+    from oracle import prng
+    torch.manual_seed(0)
+    net = network.Unet(base_ch=32).to(dev)
+    n, B = 1024, 16
+    imgs = torch.stack([torch.from_numpy(prng.uniform01(31, i, n * n).reshape(n, n).astype(np.float32) * 255) for i in range(B)])
+    labels = torch.stack([torch.from_numpy(prng.make_labels(32 + i, 1, n)[0]) for i in range(B)])
+    x = data.test_input(imgs.to(dev))
+    assert x.shape == (B, 1, 1212, 1212)
+    with torch.no_grad():
+        y = net(x)
+        assert y.shape == (B, 2, 1028, 1028) and bool(torch.isfinite(y).all())
+        mask, stats = hip_optim.crop_argmax_metrics(y, labels.to(dev))
+        scale = y.abs().max()
+        for i in (0, 7, 15):
+            yi = net(x[i:i + 1].contiguous())
+            assert ((yi[0] - y[i]).abs().max() / scale).item() < 2e-6
+            mi, si = hip_optim.crop_argmax_metrics(yi, labels[i:i + 1].to(dev))
+            margin = (yi[0, 0] - yi[0, 1]).abs()
+            pad = (1028 - n) // 2
+            safe = margin[pad:pad + n, pad:pad + n] > 1e-5 * scale
+            assert bool((mi[0][safe] == mask[i][safe]).all())
+            assert (si[0] - stats[i]).abs().max().item() <= int((~safe).sum())

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libunet_hip.so does not export %s" % name
     assert sorted(_hip.EXPORTS) == declared          # the ctypes table covers the whole header
-    assert L.unet_abi_version() == 1
+    assert L.unet_abi_version() == 2
 
 
 def test_size_contract_no_gpu_needed():
@@ -71,6 +71,25 @@ def test_functions_known_answers(golden_dir):
     from oracle import prng
     lab = torch.from_numpy(prng.make_labels(3, 2, 36)[:, 0])
     assert np.array_equal(functions.class_balance(lab).numpy(), ka["class_balance_rand"])
+
+
+def test_trainer_goal_identity_semantics(golden_dir):
+    """trainer.py:18-27: `DATASET is '<literal>'`.  Pinned against the reference's own run (trainer_golden.json):
+    only a caller's literal 'ISBI2012' arms the goal."""
+    import json
+    import trainer
+    gold = json.load(open(os.path.join(golden_dir, "trainer_golden.json")))["cases"]
+    assert trainer._goal_for("ISBI2012") == (1, 0.0611) and gold["literal_ISBI2012"]["goal_lines"]
+    assert trainer._goal_for("".join(["ISBI", "2012"])) == (None, None) and not gold["runtime_ISBI2012"]["goal_lines"]
+    assert trainer._goal_for("DIC-C2DH-HeLa") == (None, None) and not gold["literal_DIC-C2DH-HeLa"]["goal_lines"]
+    assert "models/unet_weight_save_ISBI2012.pth" in gold["literal_ISBI2012"]["files"]
+    assert "models/unet_weight_save_latest.pth" not in gold["literal_ISBI2012"]["files"]
+
+
+def test_rccl_binds_without_a_gpu():
+    import _hip
+    assert _hip.lib().unet_dp_rccl_version() > 20000          # librccl found and its symbols bound (no communicator yet)
+    assert _hip.lib().unet_dp_world(None) == 0
 
 
 def test_grad_buckets_layout():

@@ -6,9 +6,14 @@ Tolerances (north_star "within 1e-3 rel fp32"): errors are normalised
   forward logits <= 2e-5 (measured 3-5e-6; the reference's own fp32 CPU run sits at ~1e-6).
   gradients, SAME branch (same ReLU masks / pool winners as the HIP forward) <= 3e-4 per tensor: the
       rigorous check of every backward kernel (oracle/parity.py explains why the branch is pinned).
-  gradients, free-running fp64 <= 5e-2: any fp32 evaluation, the reference's own included, lands on a
-      different ReLU/pool piece for a few near-zero activations; one such element moves whole tensors
-      by ~1e-2 (measured here and with the plain-C fp32 oracle), so this bound only catches gross errors.
+  gradients, free-running, against the reference's fp64 goldens: any fp32 evaluation, the reference's own
+      included, lands on a different ReLU/pool piece for a few near-zero activations, and one such element moves
+      whole upstream tensors by up to ~1e-2.  So the free-running check is an ACCOUNTING, not a loose bound
+      (test_free_running_gradients_are_explained_by_legitimate_branch_choices): (a) every element where the HIP
+      branch differs from the fp64 branch missed the decision boundary by no more than the forward rounding error,
+      (b) per tensor the distance to the reference's golden is within 2x the larger of the reference's own
+      fp32-vs-fp64 distance (recorded in the fixture) and the exact fp64 effect of the HIP branch.
+      GRAD_TOL_FREE (1e-2) remains only for the full-size tests that have no fp64 golden.
 argmax masks: bit-exact on every pixel whose fp64 margin exceeds the recorded threshold."""
 import os
 
@@ -20,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 2e-5
 GRAD_TOL = 3e-4          # same-branch
-GRAD_TOL_FREE = 5e-2     # free-running (ReLU/pool flips allowed)
+GRAD_TOL_FREE = 1e-2     # free-running where no fp64 golden exists (fp32-vs-fp32 at S=572; measured 2e-3)
 
 
 @pytest.fixture(scope="module")
@@ -60,14 +65,7 @@ def test_forward_backward_vs_reference_golden(net, golden_dir, S):
     logits, grads = run(net, S, 2, True)
     assert nerr(logits, g["logits_f64"]) < FWD_TOL
     names = [str(n) for n in g["names"]]
-    sums, samp, idx = g["grad_sums_f64"], g["grad_samp_f64"], g["grad_samp_idx"]
-    for i, k in enumerate(names):
-        a = grads[k].astype(np.float64).ravel()
-        l2 = np.sqrt((a * a).sum())
-        assert abs(l2 - sums[i, 1]) <= GRAD_TOL_FREE * sums[i, 1], (k, l2, sums[i, 1])
-        assert np.abs(a[idx[i]] - samp[i]).max() <= GRAD_TOL_FREE * sums[i, 2], k
-    for k in ("conv11c.weight", "conv11c.bias", "finalconv.weight", "finalconv.bias", "conv52c.bias", "upconv4.bias"):
-        assert nerr(grads[k], g["grad_full_%s_f64" % k]) < GRAD_TOL_FREE, k
+    assert set(names) == set(grads)
     # the head's gradients do not pass through any ReLU/pool decision: tight against the reference
     assert nerr(grads["finalconv.weight"], g["grad_full_finalconv.weight_f64"]) < 2e-5
     assert nerr(grads["finalconv.bias"], g["grad_full_finalconv.bias_f64"]) < 2e-5
@@ -86,6 +84,33 @@ def test_every_gradient_element_on_same_branch_vs_c_oracle_f64(net, S, B):
     assert r["fwd"] < FWD_TOL, r["fwd"]
     worst = max(r["grads"].items(), key=lambda kv: kv[1])
     assert worst[1] < GRAD_TOL, worst
+
+
+@pytest.mark.parametrize("S", [188, 220])
+def test_free_running_gradients_are_explained_by_legitimate_branch_choices(golden_dir, S):
+    """Free-running HIP gradients against the reference's fp64 goldens (see the module docstring)."""
+    from oracle import parity
+    g = np.load(os.path.join(golden_dir, "unet_S%d.npz" % S))
+    r = parity.check_same_branch(S, 2)
+    # (a) the HIP forward only leaves the fp64 branch where fp64 itself is within rounding of the boundary
+    n_relu, n_pool, worst = parity.branch_disagreements(r["masks"], r["sels"], S, 2)
+    print("S=%d: %d ReLU and %d pool decisions differ from fp64; largest fp64 margin among them %.2e of the layer scale" % (S, n_relu, n_pool, worst))
+    assert worst < FWD_TOL, (n_relu, n_pool, worst)
+    # (b) per tensor: |HIP - golden| <= 2 max(reference's own fp32-vs-fp64, exact fp64 effect of that branch) (+ kernel rounding)
+    names = [str(n) for n in g["names"]]
+    s64, samp64, samp32, idx = g["grad_sums_f64"], g["grad_samp_f64"], g["grad_samp_f32"], g["grad_samp_idx"]
+    ref_floor = (np.abs(samp32 - samp64).max(axis=1) / s64[:, 2]).max()
+    table = []
+    for i, k in enumerate(names):
+        hip = r["hip_grads"][k].astype(np.float64).ravel()[idx[i]]
+        onb = r["ref_grads"][k].astype(np.float64).ravel()[idx[i]]
+        e_hip = np.abs(hip - samp64[i]).max() / s64[i, 2]
+        e_branch = np.abs(onb - samp64[i]).max() / s64[i, 2]
+        e_ref = np.abs(samp32[i] - samp64[i]).max() / s64[i, 2]
+        table.append((k, e_hip, e_ref, e_branch))
+        assert e_hip <= 2 * max(ref_floor, e_branch) + GRAD_TOL, (k, e_hip, ref_floor, e_branch)
+    worst_t = max(table, key=lambda t: t[1])
+    print("S=%d: worst free-running tensor %s: HIP %.2e, reference fp32 %.2e, branch effect %.2e; reference floor %.2e" % ((S,) + worst_t + (ref_floor,)))
 
 
 def test_S572_forward_and_bit_exact_argmax(net, golden_dir):
@@ -231,7 +256,7 @@ dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks 
 S, Bg = 188, 4
 net = network.Unet()
 net.load_state_dict({k: torch.from_numpy(v) for k, v in prng.make_params(0).items()})
-net = net.to("cuda:0").enable_data_parallel()
+net = net.to("cuda:0").enable_data_parallel(backend="torch")     # RCCL wants one GPU per rank: gloo carries the buckets here
 x = torch.from_numpy(prng.make_input(1, Bg, S)).cuda()
 dl = torch.from_numpy(prng.make_cotangent(2, (Bg, 2, 4, 4))).cuda()
 per = Bg // world
@@ -257,7 +282,8 @@ dist.destroy_process_group()
 def test_data_parallel_module_path_two_ranks_one_gpu(tmp_path):
     """The module's DP backward (pre-scaled dlogits, per-stage bucketed async all-reduce, stream sync)
     with 2 processes sharing this box's GPU over gloo == the single-process global-batch gradient.
-    (RCCL needs one GPU per rank; the driver's N>1 runs exercise the same code with backend nccl.)"""
+    (RCCL needs one GPU per rank: test_rccl_* below runs the library's own communicator with one rank, the
+    driver's N>1 runs exercise it across GPUs.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(tmp_path, "dp_gpu_worker.py")
@@ -423,3 +449,157 @@ def test_shape_sweep_forward_backward(net, B, S):
         for i in (0, B - 1):
             yi = net(x[i:i + 1].contiguous())
             assert ((yi[0] - y[i]).abs().max() / y.abs().max()).item() < FWD_TOL
+
+
+def test_rccl_communicator_behind_the_c_abi_single_rank(net):
+    """unet_dp_* (csrc/dp.hip): unique id, ncclCommInitRank, broadcast, per-stage all-reduce on the communicator stream,
+    join.  With one rank the collectives are identities, so the gradients must equal the plain backward bit for bit —
+    what this pins is that the RCCL code path, its stream fork/join and the bucket ranges execute on the GPU."""
+    import copy
+    import ctypes as C
+    import _hip
+    import network
+    from oracle import prng
+    L = _hip.lib()
+    assert L.unet_dp_rccl_version() > 0
+    m = copy.deepcopy(net)
+    x = torch.from_numpy(prng.make_input(1, 2, 188)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(2, (2, 2, 4, 4))).cuda()
+    m.zero_grad(set_to_none=True)
+    m(x).backward(dl)
+    plain = [p.grad.clone() for p in m.parameters()]
+    before = [p.detach().clone() for p in m.parameters()]
+    m.enable_data_parallel(backend="rccl")              # no torch.distributed: a communicator of one rank
+    h = network._handle(0, m.base_ch)
+    assert L.unet_dp_world(h.h) == 1
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))        # broadcast from rank 0 == identity
+    m.zero_grad(set_to_none=True)
+    m(x).backward(dl)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.grad) for a, p in zip(plain, m.parameters()))
+    # raw entry points: SUM all-reduce of a buffer, ordered after the producer on the caller's stream
+    buf = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+    _hip.check(L.unet_dp_allreduce(h.h, _hip.ptr(buf), buf.numel(), _hip.stream()), "allreduce")
+    _hip.check(L.unet_dp_join(h.h, _hip.stream()), "join")
+    torch.cuda.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32) * 0.5)
+    _hip.check(L.unet_dp_destroy(h.h), "destroy")
+    assert L.unet_dp_world(h.h) == 0
+    assert L.unet_dp_allreduce(h.h, _hip.ptr(buf), 10, _hip.stream()) != 0                 # loud, not silent, without a communicator
+
+
+def test_training_stop_goal_follows_the_reference_identity_comparisons(net, golden_dir, tmp_path, capsys):
+    """trainer.py:18-27,185-214: a caller's literal 'ISBI2012' arms the stop goal, the same text built at run time (argv)
+    and 'DIC-C2DH-HeLa' do not.  Golden: the reference's own training() run on the same inputs
+    (tests/golden/make_golden_trainer.py): files written, goal lines, and the six progress series."""
+    import copy
+    import json
+    from oracle import prng
+    from trainer import training
+    gold = json.load(open(os.path.join(golden_dir, "trainer_golden.json")))
+    S, So = gold["meta"]["S"], gold["meta"]["S"] - 184
+
+    def loader(seeds):
+        return [(torch.from_numpy(prng.make_input(s, 2, S)), torch.from_numpy(prng.make_labels(s, 2, So))) for s in seeds]
+
+    cases = {"literal_ISBI2012": "ISBI2012", "runtime_ISBI2012": "".join(["ISBI", "2012"]), "literal_DIC-C2DH-HeLa": "DIC-C2DH-HeLa"}
+    for case, name in cases.items():
+        m = copy.deepcopy(net)
+        out = os.path.join(tmp_path, case)
+        capsys.readouterr()
+        training(m, loader(gold["meta"]["train_seeds"]), loader(gold["meta"]["val_seeds"]), gold["meta"]["epochs_arg"], 2,
+                 torch.device("cuda:0"), out, name)
+        printed = capsys.readouterr().out.splitlines()
+        want = gold["cases"][case]
+        files = sorted(os.path.relpath(os.path.join(r, f), out) for r, _, fs in os.walk(out) for f in fs)
+        assert files == want["files"], (case, files)
+        assert [ln for ln in printed if ln.startswith("The goal was reached")] == want["goal_lines"], case
+        assert sum(ln == "Model has been saved:" for ln in printed) == want["n_model_saved_lines"], case
+        for series, vals in want["progress"].items():
+            got = np.atleast_1d(np.loadtxt(os.path.join(out, "progress", series + ".out")))
+            # losses: fp32 step on another device; metrics: integer counts of a 4x4 mask (exact unless a logit margin is at rounding level)
+            assert np.allclose(got, vals, rtol=2e-3, atol=1e-6), (case, series, got, vals)
+
+
+def test_checkpoint_resume_with_momentum_is_bit_exact(net, tmp_path):
+    """the reference saves weights only; checkpoint.py adds the SGD momentum buffers.  An interrupted-and-resumed
+    run must be the uninterrupted run, bit for bit; resuming from weights alone (the reference's format) must not be."""
+    import copy
+    import checkpoint
+    import optim as hip_optim
+    from oracle import prng
+    x = torch.from_numpy(prng.make_input(1, 2, 188)).cuda()
+    tgt = hip_optim.onehot2(torch.from_numpy(prng.make_labels(3, 2, 4)), torch.empty(2, 2, 4, 4, device="cuda"))
+
+    def steps(m, opt, n):
+        for _ in range(n):
+            opt.zero_grad(set_to_none=True)
+            hip_optim.bce_with_logits(m(x), tgt).backward()
+            opt.step()
+
+    a = copy.deepcopy(net); oa = hip_optim.SGD(a.parameters(), lr=1e-4, momentum=0.99)
+    steps(a, oa, 2)
+    path = checkpoint.save_checkpoint(os.path.join(tmp_path, "ck.pth"), a, oa, epoch=7)
+    torch.save(a.state_dict(), os.path.join(tmp_path, "weights_only.pth"))
+    steps(a, oa, 2)
+    b = copy.deepcopy(net); ob = hip_optim.SGD(b.parameters(), lr=1e-4, momentum=0.99)
+    extra = checkpoint.load_checkpoint(path, b, ob)
+    assert extra["epoch"] == 7
+    steps(b, ob, 2)
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    c = copy.deepcopy(net); oc = hip_optim.SGD(c.parameters(), lr=1e-4, momentum=0.99)
+    assert checkpoint.load_checkpoint(os.path.join(tmp_path, "weights_only.pth"), c, oc) == {}      # a reference-format file loads too
+    steps(c, oc, 2)
+    assert any(not torch.equal(p, q) for p, q in zip(a.parameters(), c.parameters()))             # ...but the momentum is gone
+    assert checkpoint.find_resume_checkpoint(str(tmp_path)) is None
+
+
+def test_arithmetic_mode_is_fixed_per_forward(net, math_mode):
+    """The mode is read when a forward is planned and kept with its plan: changing the process default between a
+    forward and its backward (another thread's call, a scheduler) must not change that backward."""
+    from oracle import prng
+    x = torch.from_numpy(prng.make_input(1, 2, 188)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(2, (2, 2, 4, 4))).cuda()
+    math_mode(3)
+    net.zero_grad(set_to_none=True)
+    net(x).backward(dl)
+    ref = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    y = net(x)
+    math_mode(0)
+    y.backward(dl)
+    assert all(torch.equal(a, p.grad) for a, p in zip(ref, net.parameters()))
+
+
+def test_config3_arithmetic_at_its_real_size(math_mode):
+    """BASELINE configs[2] per-GPU work: batch 8 x 572^2 in bf16 compute (mode 2).  Same-branch fp64 oracle at S=380 (the
+    largest size the oracle finishes in seconds), then at B=8 x 572 the size-independent properties: batch independence of
+    the logits and additivity of the gradients over a ragged split of the batch."""
+    import network
+    from oracle import parity, prng
+    math_mode(2)
+    r = parity.check_same_branch(380, 1)
+    assert r["fwd"] < 5e-2, r["fwd"]
+    assert max(r["grads"].values()) < 6e-2
+    m = network.Unet()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in prng.make_params(0).items()})
+    m = m.to("cuda:0")
+    S, B = 572, 8
+    x = torch.from_numpy(prng.make_input(5, B, S)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(6, (B, 2, 388, 388))).cuda()
+    y = m(x)
+    y.backward(dl)
+    g_all = [p.grad.clone() for p in m.parameters()]
+    assert bool(torch.isfinite(y).all())
+    with torch.no_grad():
+        y0 = m(x[0:1].contiguous()); y7 = m(x[7:8].contiguous())
+    scale = y.abs().max()
+    assert ((y0[0] - y[0]).abs().max() / scale).item() < 1e-5 and ((y7[0] - y[7]).abs().max() / scale).item() < 1e-5
+    acc = None
+    for lo, hi in ((0, 3), (3, 8)):
+        m.zero_grad(set_to_none=True)
+        m(x[lo:hi].contiguous()).backward(dl[lo:hi].contiguous())
+        part = [p.grad.clone() for p in m.parameters()]
+        acc = part if acc is None else [a + b for a, b in zip(acc, part)]
+    for a, b in zip(acc, g_all):
+        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < 1e-3     # same bf16 products, fp32 sums in another order

@@ -52,12 +52,17 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
 
 
-@pytest.fixture(params=[0, 3], ids=["direct", "winograd"])
+@pytest.fixture(params=[(0, 1), (3, 1), (0, 0), (3, 0)], ids=["direct", "winograd", "direct-glds", "winograd-glds"])
 def conv_mode(hip, request):
-    """The 3x3 layers have two fp32 evaluations: the direct fmaf chain (math mode 0) and Winograd F(2x2,3x3) (mode 3)."""
+    """The 3x3 layers have two fp32 evaluations: the direct fmaf chain (math mode 0) and Winograd F(2x2,3x3) (mode 3);
+    each stages its operands either by buffer-descriptor LDS-DMA (default) or by global_load_lds — the instantiation
+    tensors >= 2 GiB take (BASELINE config #5 at batch 16), forced here with unet_set_lds_dma(0)."""
+    mode, dma = request.param
     default = hip.lib().unet_get_math()
-    hip.check(hip.lib().unet_set_math(request.param), "set_math")
-    yield request.param
+    hip.check(hip.lib().unet_set_math(mode), "set_math")
+    hip.check(hip.lib().unet_set_lds_dma(dma), "set_lds_dma")
+    yield mode
+    hip.check(hip.lib().unet_set_lds_dma(1), "set_lds_dma")
     hip.check(hip.lib().unet_set_math(default), "set_math")
 
 
@@ -82,33 +87,6 @@ def test_conv3x3_random_shapes(hip):
     spec = importlib.util.spec_from_file_location("fuzz_conv", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_conv.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     assert fz.run(30, 11, verbose=False) < TOL
-
-
-@pytest.mark.parametrize("B,H,C,K", [(2, 45, 64, 64), (1, 66, 512, 512)])
-def test_conv3x3_wide_winograd_variant(hip, B, H, C, K, monkeypatch):
-    """The 512-thread, 64-channel-wide Winograd kernel (UNET_WINO32=0; the default is the half-width one): forward and
-    dgrad against fp64."""
-    monkeypatch.setenv("UNET_WINO32", "0")
-    default = hip.lib().unet_get_math()
-    hip.check(hip.lib().unet_set_math(3), "set_math")
-    try:
-        keep = Keep()
-        x = rnd(B, C, H, H, seed=1).requires_grad_(True); w = rnd(K, C, 3, 3, seed=2, scale=0.05).requires_grad_(True); b = rnd(K, seed=3)
-        dz = rnd(B, K, H - 2, H - 2, seed=4)
-        z = F.conv2d(x, w, b)
-        z.backward(dz)
-        y = torch.empty(B, H - 2, H - 2, K, device="cuda")
-        sc = scratch(hip.lib().unet_conv3x3_scratch_bytes(C, K))
-        hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc(x.detach()))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.detach().float().cuda())),
-                                             hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc), hip.stream()), "conv3x3_fwd")
-        assert nerr(nchw(y), F.relu(z.detach())) < TOL
-        dx = torch.empty(B, H, H, C, device="cuda")
-        sc2 = scratch(hip.lib().unet_conv3x3_bwd_scratch_bytes(B, H, H, C, K))
-        hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(keep(nhwc(x.detach()))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.detach().float().cuda())), K,
-                                             hip.ptr(keep(nhwc(dz))), hip.ptr(dx), None, None, None, None, None, None, hip.ptr(sc2), hip.stream()), "conv3x3_bwd")
-        assert nerr(nchw(dx), x.grad) < TOL
-    finally:
-        hip.check(hip.lib().unet_set_math(default), "set_math")
 
 
 @pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128),
@@ -247,10 +225,10 @@ def test_head1x1_fwd_bwd(hip):
     assert nerr(db, dl.sum((0, 2, 3))) < TOL
 
 
-def test_conv1ch_fwd_bwd_vs_c_oracle(hip):
+@pytest.mark.parametrize("B,S,K", [(2, 44, 64), (1, 188, 64), (3, 60, 32), (1, 572, 64)])
+def test_conv1ch_fwd_bwd_vs_c_oracle(hip, B, S, K):
     keep = Keep()
     from oracle import oracle_c
-    B, S, K = 2, 45, 64
     x = rnd(B, 1, S, S, seed=1).float(); w = rnd(K, 1, 3, 3, seed=2).float(); b = rnd(K, seed=3).float()
     ref = oracle_c.conv_valid_fwd(x.double().numpy(), w.double().numpy(), b.double().numpy(), True)
     y = torch.empty(B, S - 2, S - 2, K, device="cuda")
@@ -312,3 +290,18 @@ def test_step_side_kernels(hip, golden_dir):
         hip.check(L.unet_sgd_momentum(hip.ptr_table(ps), hip.ptr_table(gs), hip.ptr_table(bufs), numel, 3, 1e-4, 0.99, int(step == 0), hip.stream()))
     for p, r in zip(ps, ref):
         assert torch.allclose(p, r.detach(), rtol=0, atol=5e-7)      # <= 1 ulp at |p| ~ 4 (fma vs mul+add)
+    # pointers that are not 16-byte aligned take the 4-byte kernel: same result
+    base = [torch.randn(n + 1, device="cuda") for n in (5000, 70001)]
+    ps2 = [b[1:] for b in base]
+    ref2 = [torch.nn.Parameter(p.clone()) for p in ps2]
+    opt2 = torch.optim.SGD(ref2, lr=1e-4, momentum=0.99)
+    bufs2 = [torch.zeros_like(p) for p in ps2]
+    numel2 = (C.c_size_t * 2)(*[p.numel() for p in ps2])
+    for step in range(2):
+        gs = [torch.randn_like(p) for p in ps2]
+        for r, gg in zip(ref2, gs):
+            r.grad = gg.clone()
+        opt2.step()
+        hip.check(L.unet_sgd_momentum(hip.ptr_table(ps2), hip.ptr_table(gs), hip.ptr_table(bufs2), numel2, 2, 1e-4, 0.99, int(step == 0), hip.stream()))
+    for p, r in zip(ps2, ref2):
+        assert torch.allclose(p, r.detach(), rtol=0, atol=5e-7)

@@ -13,8 +13,8 @@ def short(n):
     return n.split("(")[0].replace("void ", "").replace("unet::", "")[:44]
 
 stats = list(csv.DictReader(open("profiles/%s_rocprofv3_kernel_stats.csv" % tag)))
-DOM = (("wino", "wino"), ("igemm", "igemm_f32_kernel"))     # kernels whose traffic / launch time are reported ("wino": wino_f32_kernel + wino32_f32_kernel)
-EXCL = ("wino_transform",)
+DOM = (("wino", "wino32"), ("igemm", "igemm"), ("wgrad", "wgrad"))     # kernel families whose traffic / launch time are reported
+EXCL = ("wino_transform", "reduce")
 calls = {}; ns = {}
 for key, sub in DOM:
     rs = [r for r in stats if sub in r["Name"] and not any(e in r["Name"] for e in EXCL)]
@@ -36,15 +36,16 @@ def counters(sub):
 sq, nsq, dur = counters("sq"); fe, nfe, _ = counters("fetch"); wr, nwr, _ = counters("write"); ld, nld, _ = counters("lds")
 lines = ["# %s — rocprofv3 PMC summary (bench.py --steps 2 --warmup 1, separate --pmc passes)" % tag, "",
          "FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM); units MB.",
-         "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock); clock = GRBM_GUI_ACTIVE / 8 / duration.", "",
-         "| kernel | launches | ms total | clock GHz | MFMA busy | WAIT_ANY/WAVE | fetch MB/launch (x2) | write MB/launch | LDS bank-conflict cycles / LDS active |",
+         "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock); clock = GRBM_GUI_ACTIVE / 8 / duration.",
+         "LDS conflict ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra cycles / all LDS-array cycles, MI355X_MICROARCH.md LDS section).", "",
+         "| kernel | launches | ms total | clock GHz | MFMA busy | WAIT_ANY/WAVE | fetch MB/launch (x2) | write MB/launch | LDS conflict ratio |",
          "|---|---|---|---|---|---|---|---|---|"]
 tot_f = collections.Counter(); tot_w = collections.Counter(); tot_n = collections.Counter()
 for k in sorted(dur, key=lambda k: -dur[k])[:24]:
     c = sq[k]; clk = c["GRBM_GUI_ACTIVE"] / 8 / dur[k] if dur[k] else 0
     busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * dur[k] * clk) if clk else 0
     f = 2 * fe[k]["FETCH_SIZE"] / 1024 / max(nfe[k], 1); w = wr[k]["WRITE_SIZE"] / 1024 / max(nwr[k], 1)
-    lb = ld[k]["SQ_LDS_BANK_CONFLICT"] / max(ld[k]["SQ_ACTIVE_INST_LDS"], 1)
+    lb = ld[k]["SQ_LDS_BANK_CONFLICT"] / max(ld[k]["SQ_LDS_IDX_ACTIVE"], 1)
     lines.append("| %s | %d | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.3f |" % (k, nsq[k], dur[k] / 1e6, clk, busy,
                  c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1), f, w, lb))
     for key, sub in DOM:
@@ -52,7 +53,7 @@ for k in sorted(dur, key=lambda k: -dur[k])[:24]:
             tot_f[key] += 2 * fe[k]["FETCH_SIZE"] / 1024; tot_w[key] += wr[k]["WRITE_SIZE"] / 1024; tot_n[key] += nfe[k]
 out = {"source": "profiles/%s_pmc_summary.md" % tag}
 lines.append("")
-bench_dom = "wino" if "wino" in bench["roofline"]["kernel"] else "igemm"
+bench_dom = "wino" if "wino" in bench["roofline"]["kernel"] else "igemm" if "igemm" in bench["roofline"]["kernel"] else "wgrad"
 for key, sub in DOM:
     if not tot_n[key]:
         continue
