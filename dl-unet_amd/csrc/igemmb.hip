@@ -1,0 +1,327 @@
+// igemmb.hip — implicit GEMM on the bf16 matrix cores with bf16 tensors in HBM (arithmetic mode 2, BASELINE config #3):
+// activations, their gradients and the packed filters are bf16 (2 B/element), accumulation is fp32
+// (v_mfma_f32_32x32x16_bf16), bias is fp32, the epilogue rounds once to bf16 (RNE).
+//
+// Same contraction family as igemm.hip (conv3x3 fwd / dgrad over the virtual concat, up-conv fwd / dgrad; network.py:131-188
+// and their autograd) and the same descriptor (IgemmP; tensor pointers are bf16 here), but built for the 16x faster pipe:
+//   * operands go HBM -> LDS by LDS-DMA through buffer descriptors, bf16 as stored: no VGPR round trip, no conversion;
+//   * an LDS row is 128 B = 64 channels of one pixel (or 64 K entries of one filter row), 16-byte chunks XOR-swizzled with
+//     (row >> 1) & 7 on the DMA source address and on the fragment read: a ds_read_b128 IS one 32x32x16 operand fragment
+//     (lane (r, h) holds k = 8h .. 8h+7 of row r) and the reads are bank-conflict free;
+//   * K step = 64 channels of one tap (4 MFMA k-steps), double buffered, one barrier per step;
+//   * epilogue: each wave transposes its 32 x 64 accumulator slabs through LDS and stores 16 bytes per lane (8 channels),
+//     128 contiguous bytes per pixel row, with bias / +add / ReLU (deferred-ReLU window) / ReLU' mask fused.
+// What bounds it: staging.  A 128x128 tile needs (128+128) x 128 B per 512 MFMA cycles per wave = 64 B/clk/CU at two
+// workgroups per CU against the ~29 B/clk/CU a CU takes in from L2 (MI355X_MICROARCH.md, "Indexed rows"); the 3x3
+// layers therefore use the halo-tile kernel below, which fetches an input pixel once for all 9 taps.
+#include "common.hpp"
+#include "igemm_epilogue.hpp"
+#include <cstdio>
+#include <cstdlib>
+
+namespace unet {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ void bbuf_lds16(__amdgpu_buffer_rsrc_t r, unsigned char *lds, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+
+// ---- epilogue -----------------------------------------------------------------------------------------------------------
+// acc[tm][tn]: 32x32 tiles of the wave's 64x64 block (rows = pixels, columns = output channels; C/D layout: column = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Per tm the wave writes its 32 x 64 slab to a private LDS patch (row pitch 68
+// floats: 16-B aligned rows, conflict-free b128 read-back) and reads it back as rows: lane -> (row = lane >> 3 + 8k, 8 channels).
+constexpr int EPB_PITCH = 68;
+constexpr int EPB_WAVE_BYTES = 32 * EPB_PITCH * 4;          // 8704
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
+{
+    constexpr int WN = BN / 64;
+    unsigned *rowoff = (unsigned *)lds;                                   // [BM] element offset of each tile row's pixel in dst
+    unsigned char *inwin = lds + BM * 4;                                  // [BM] deferred-ReLU flags
+    float *patch0 = (float *)(lds + BM * 4 + ((BM + 15) & ~15));
+    if (tid < BM) {
+        const bool relu_win = p.rw1 > p.rw0;
+        int m = m0 + tid;
+        m = m < p.M ? m : p.M - 1;
+        unsigned off;
+        unsigned char flag = 0;
+        if (!p.scatter && !relu_win) {
+            off = (unsigned)m * (unsigned)p.DC;
+        } else {
+            const int ohw = p.OH * p.OW;
+            const int img = fdiv(m, p.d_ohw);
+            const int rem = m - img * ohw;
+            const int oy = fdiv(rem, p.d_ow);
+            const int ox = rem - oy * p.OW;
+            if (p.scatter == 1) off = (unsigned)((img * p.DH + 2 * oy) * p.DW + 2 * ox) * (unsigned)p.DC;
+            else if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
+            else off = (unsigned)m * (unsigned)p.DC;
+            flag = relu_win && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
+        }
+        rowoff[tid] = off;
+        inwin[tid] = flag;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    float *patch = patch0 + wave * (EPB_WAVE_BYTES / 4);
+    const bool relu_win = p.rw1 > p.rw0;
+    const int rrow = lane >> 3, cg = lane & 7;
+    const u16 *addp = (const u16 *)p.add, *maskp = (const u16 *)p.mask;
+    u16 *dstp = (u16 *)p.dst;
+    const int nb = n0 + wn * 64;
+    float bv[2] = {0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            int n = nb + tn * 32 + l31;
+            n = n < p.Nn ? n : p.Nn - 1;
+            bv[tn] = p.bias[p.cout ? n % p.cout : n];
+        }
+    }
+    const int n8 = nb + 8 * cg;
+    const bool n_ok = n8 < p.Nn;
+    const int nc = n_ok ? n8 : 0;
+    int coloff;
+    if (p.scatter != 1) {
+        coloff = p.dn0 + nc;
+    } else {
+        const int ab = nc / p.cout;
+        coloff = ((ab >> 1) * p.DW + (ab & 1)) * p.DC + p.dn0 + (nc - ab * p.cout);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPB_PITCH + tn * 32 + l31] = acc[tm][tn][r] + bv[tn];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int trow = wm * 64 + tm * 32 + rrow + 8 * k;
+            const f32x4 lo = *(const f32x4 *)(patch + (rrow + 8 * k) * EPB_PITCH + 8 * cg);
+            const f32x4 hi = *(const f32x4 *)(patch + (rrow + 8 * k) * EPB_PITCH + 8 * cg + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const size_t o = (size_t)rowoff[trow] + (size_t)coloff;
+            if (addp) {
+                const uint4 t = *(const uint4 *)(addp + o);
+                const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { v[2 * c] += bf2f((u16)(tw[c] & 0xffff)); v[2 * c + 1] += bf2f((u16)(tw[c] >> 16)); }
+            }
+            if (p.relu) {
+                const bool defer = relu_win && inwin[trow];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = (v[c] > 0.f || defer) ? v[c] : 0.f;
+            }
+            if (maskp) {
+                const uint4 t = *(const uint4 *)(maskp + o);
+                const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // a ReLU output: positive iff its bf16 pattern is neither zero nor negative
+                    v[2 * c] = (short)(tw[c] & 0xffff) > 0 ? v[2 * c] : 0.f;
+                    v[2 * c + 1] = (short)(tw[c] >> 16) > 0 ? v[2 * c + 1] : 0.f;
+                }
+            }
+            if (n_ok && m0 + trow < p.M) {
+                uint4 w;
+                w.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                w.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                w.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                w.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                *(uint4 *)(dstp + o) = w;
+            }
+        }
+    }
+}
+
+// ---- plain kernel: every tap re-stages its A rows (up-conv GEMMs, and any 3x3 shape the halo kernel does not take) -------
+template <int BM, int BN, bool PAD>
+__global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
+{
+    constexpr int WN = BN / 64;
+    constexpr int WM = 4 / WN;
+    static_assert(WM * 64 == BM, "4 waves of 64x64");
+    constexpr int RA = BM / 32, RB = BN / 32;   // staging rows per thread
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int mt = logical / p.ntiles, nt = logical - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // staging geometry: thread -> (row within a 32-row pass, 16-B chunk position); the SOURCE chunk is the swizzled one
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int coff = schunk * 8;                          // bf16 elements
+
+    int a_off[RA], a_iy[RA], a_ix[RA];
+    int b_off[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        int n = n0 + srow + 32 * j;
+        n = n < p.Nn ? n : p.Nn - 1;
+        b_off[j] = (n * p.ldw + coff) * 2;                // bytes
+    }
+
+    int s = 0, ty = 0, tx = 0, kc = 0, kglob = 0;
+    int sH = 0, sW = 0, sC = 0, snch = 0, toff = 0;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, p.buf_bytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, p.buf_bytes[2], 0x00020000);
+    auto setup_source = [&](int si) {
+        const GSrc &g = p.src[si];
+        sH = g.H; sW = g.W; sC = g.C; snch = g.nch;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)g.p, 0, p.buf_bytes[si], 0x00020000);
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int m = m0 + srow + 32 * i;
+            m = m < p.M ? m : p.M - 1;
+            const int img = fdiv(m, p.d_ohw);
+            const int rem = m - img * ohw;
+            const int oy = fdiv(rem, p.d_ow);
+            const int ox = rem - oy * p.OW;
+            const int iy = (oy + p.oy0) * p.stride - g.pad;
+            const int ix = (ox + p.ox0) * p.stride - g.pad;
+            a_iy[i] = iy; a_ix[i] = ix;
+            a_off[i] = (((img * g.H + iy) * g.W + ix) * g.C + g.c0 + coff) * 2;      // bytes
+        }
+        toff = 0;
+    };
+    auto stage = [&](int buf) {
+        unsigned char *abase = smem + buf * STAGE + wave * (8 * 128);
+        unsigned char *bbase = abase + A_BYTES;
+        const int so = (toff + kc) * 2;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int vo = a_off[i];
+            if (PAD) {
+                const bool inb = (unsigned)(a_iy[i] + ty) < (unsigned)sH && (unsigned)(a_ix[i] + tx) < (unsigned)sW;
+                vo = inb ? vo : (int)0x80000000;
+            }
+            bbuf_lds16(rs_a, abase + i * (32 * 128), vo, so);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) bbuf_lds16(rs_b, bbase + j * (32 * 128), b_off[j], kglob * 2);
+    };
+    auto advance = [&]() {
+        kglob += 64;
+        kc += 64;
+        if (kc == snch) {
+            kc = 0;
+            ++tx;
+            if (tx == p.TX) { tx = 0; ++ty; }
+            if (ty * p.TX + tx == p.T) {
+                ty = 0; tx = 0;
+                ++s;
+                if (s < p.nsrc) setup_source(s);
+            } else {
+                toff = (ty * sW + tx) * sC;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int a_rd = (wm * 64 + l31) * 128;
+    const int b_rd = A_BYTES + (wn * 64 + l31) * 128;
+
+    const int nk = p.Kd >> 6;
+    setup_source(0);
+    stage(0);
+    advance();
+    __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes buffer 0
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) { stage(cur ^ 1); advance(); }
+        const unsigned char *sb = smem + cur * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int pos = ((2 * g + lh) ^ swz) * 16;
+            const bf16x8 a0 = *(const bf16x8 *)(sb + a_rd + pos);
+            const bf16x8 a1 = *(const bf16x8 *)(sb + a_rd + 32 * 128 + pos);
+            const bf16x8 b0 = *(const bf16x8 *)(sb + b_rd + pos);
+            const bf16x8 b1 = *(const bf16x8 *)(sb + b_rd + 32 * 128 + pos);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
+    }
+    igemmb_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
+}
+
+template <int BM, int BN, bool PAD>
+static int launch_cfgb(const IgemmP &p, hipStream_t st)
+{
+    constexpr int STAGES = 2 * (BM + BN) * 128;
+    constexpr int EPI = BM * 4 + ((BM + 15) & ~15) + 4 * EPB_WAVE_BYTES;
+    constexpr int LDS = STAGES > EPI ? STAGES : EPI;
+    static bool attr_done[64] = {false};
+    auto kern = igemmb_kernel<BM, BN, PAD>;
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, attr_done)) return rc_;
+    IgemmP q = p;
+    q.mtiles = cdiv(p.M, BM);
+    q.ntiles = cdiv(p.Nn, BN);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "igemmb<%d;%d;%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
+    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * q.mtiles * BM * (double)q.ntiles * BN * p.Kd, igemm_alg_bytes(p));
+    hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// p has passed launch_igemm's generic checks; tensors are bf16
+int launch_igemmb(IgemmP p, bool pad, hipStream_t st)
+{
+    for (int i = 0; i < p.nsrc; ++i) {
+        ARG_CHECK(p.src[i].nch % 64 == 0, "igemmb: channel count %d is not a multiple of 64", p.src[i].nch);
+        ARG_CHECK(p.src[i].C % 8 == 0 && p.src[i].c0 % 8 == 0, "igemmb: channel pitch/offset must be multiples of 8");
+    }
+    ARG_CHECK(p.ldw % 8 == 0 && p.DC % 8 == 0 && p.dn0 % 8 == 0 && p.Nn % 8 == 0 && (!p.scatter || p.cout % 8 == 0), "igemmb: 16-byte accesses need channel counts that are multiples of 8");
+    ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemmb: destination exceeds 31-bit element offsets");
+    for (int i = 0; i < 3; ++i) p.buf_bytes[i] = 0;
+    for (int i = 0; i < p.nsrc; ++i) {
+        const size_t b = (size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C * 2;
+        ARG_CHECK(b < 0x7FFFFFFFull, "igemmb: source tensor exceeds 2 GiB");
+        p.buf_bytes[i] = (int)b;
+    }
+    {
+        const size_t b = (size_t)p.Nn * p.ldw * 2;
+        ARG_CHECK(b < 0x7FFFFFFFull, "igemmb: filter matrix exceeds 2 GiB");
+        p.buf_bytes[2] = (int)b;
+    }
+    if (p.Nn % 128 == 0) return pad ? launch_cfgb<128, 128, true>(p, st) : launch_cfgb<128, 128, false>(p, st);
+    return pad ? launch_cfgb<256, 64, true>(p, st) : launch_cfgb<256, 64, false>(p, st);
+}
+
+}  // namespace unet
