@@ -41,6 +41,7 @@ _SIGS = {
     "unet_backward_stage": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]),
     "unet_backward_stage_params": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
     "unet_flops": (C.c_double, [vp, C.c_int, C.c_int, C.c_int]),
+    "unet_activation_bytes": (C.c_int, [vp]),
     "unet_debug_buffer": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "unet_profile_enable": (C.c_int, [C.c_int]),
     "unet_profile_reset": (C.c_int, []),
@@ -182,7 +183,8 @@ class Handle:
         check(lib().unet_debug_buffer(self._h, B, S, int(training), name.encode(), C.byref(off), C.byref(e), C.byref(c)),
               "unet_debug_buffer")
         n = B * e.value * e.value * c.value
-        return ws[off.value:off.value + 4 * n].view(torch.float32).view(B, e.value, e.value, c.value)
+        eb = 4 if name == "xin" else lib().unet_activation_bytes(self._h)          # bf16 tensors in arithmetic mode 2
+        return ws[off.value:off.value + eb * n].view(torch.bfloat16 if eb == 2 else torch.float32).view(B, e.value, e.value, c.value)
 
     def flops(self, B, S, backward):
         return lib().unet_flops(self._h, B, S, int(backward))

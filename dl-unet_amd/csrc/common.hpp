@@ -142,12 +142,22 @@ double wgrad_alg_flops(const WgradP &p);
 double wgrad_alg_bytes(const WgradP &p);
 int launch_wgrad(WgradP p, hipStream_t st);
 
-// Packers from the reference's parameter layouts into the igemm weight matrices (direct.hip)
-int pack_conv_fwd(const float *w_oihw, float *wt, int K, int C1, int C2, hipStream_t st);   // [K][9*C1 | 9*C2]
-int pack_conv_dgrad(const float *w_oihw, float *wt, int K, int C, hipStream_t st);          // [C][9*K], taps flipped
-int pack_upconv_fwd(const float *w_iohw, float *wt, int Ci, int Co, hipStream_t st);        // [4*Co][Ci]
-int pack_upconv_dgrad(const float *w_iohw, float *wt, int Ci, int Co, hipStream_t st);      // [Ci][4*Co]
-int bias_grad(const float *dz, size_t M, int K, float *db, float *scratch, hipStream_t st); // db[k] = sum_m dz[m][k]
+// Packers from the reference's parameter layouts into the igemm weight matrices (direct.hip); es = element size of the
+// packed matrix: 4 (fp32) or 2 (bf16, arithmetic mode 2)
+int pack_conv_fwd(const float *w_oihw, void *wt, int K, int C1, int C2, int es, hipStream_t st);   // [K][9*C1 | 9*C2]
+int pack_conv_dgrad(const float *w_oihw, void *wt, int K, int C, int es, hipStream_t st);          // [C][9*K], taps flipped
+int pack_upconv_fwd(const float *w_iohw, void *wt, int Ci, int Co, int es, hipStream_t st);        // [4*Co][Ci]
+int pack_upconv_dgrad(const float *w_iohw, void *wt, int Ci, int Co, int es, hipStream_t st);      // [Ci][4*Co]
+int bias_grad(const void *dz, size_t M, int K, float *db, float *scratch, int es, hipStream_t st); // db[k] = sum_m dz[m][k]
 size_t bias_grad_scratch_bytes(size_t M, int K);
+
+// HBM-bound layers (direct.hip); es = element size of the activation tensors (4: fp32, 2: bf16)
+int conv1ch_fwd(const float *x, int B, int S, const float *w, const float *bias, int K, void *y, int es, hipStream_t st);
+int conv1ch_bwd(const float *x, int B, int S, int K, const void *dz, float *dw, float *db, float *scratch, int es, hipStream_t st);
+int head1x1_fwd(const void *x, int B, int H, int W, int C, const float *w, const float *bias, float *logits, int es, hipStream_t st);
+int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, void *dz, float *dw, float *db,
+                float *scratch, int es, hipStream_t st);
+int maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, int es, hipStream_t st);
+int maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, int es, hipStream_t st);
 
 }  // namespace unet

@@ -8,6 +8,26 @@
 namespace unet {
 
 typedef float float4_ __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;          // storage type of arithmetic mode 2: bf16 bit patterns
+
+// 4 consecutive channels of a tensor stored as T (float: 16 B, bf16: 8 B), as floats
+__device__ __forceinline__ float4_ load4(const float *p) { return *(const float4_ *)p; }
+__device__ __forceinline__ float4_ load4(const bf16_t *p)
+{
+    const uint2 w = *(const uint2 *)p;
+    return float4_{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                   __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void put1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void put1(bf16_t *p, float v) { *p = __builtin_bit_cast(bf16_t, (__bf16)v); }
+__device__ __forceinline__ void store4(float *p, float4_ v) { *(float4_ *)p = v; }
+__device__ __forceinline__ void store4(bf16_t *p, float4_ v)
+{
+    uint2 w;
+    w.x = (unsigned)__builtin_bit_cast(bf16_t, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(bf16_t, (__bf16)v[1]) << 16);
+    w.y = (unsigned)__builtin_bit_cast(bf16_t, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(bf16_t, (__bf16)v[3]) << 16);
+    *(uint2 *)p = w;
+}
 
 // ============================================================================================
 // conv11c: x [B,S,S] (C=1) -> y [B,S-2,S-2,K] NHWC, + bias + ReLU.        network.py:23,131 (A1)
@@ -17,9 +37,9 @@ typedef float float4_ __attribute__((ext_vector_type(4)));
 // so every store instruction writes 4 (K=64) whole pixels = 1 KiB contiguous.  No per-pixel index arithmetic beyond
 // one add: the row decomposition is one scalar division per row.
 // ============================================================================================
-template <int K>
+template <int K, typename T>
 __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                          const float *__restrict__ bias, float *__restrict__ y,
+                                                          const float *__restrict__ bias, T *__restrict__ y,
                                                           int S, int nrows)
 {
     constexpr int CG = K / 4;                 // lanes per pixel
@@ -42,7 +62,7 @@ __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restric
         __syncthreads();                      // the previous row's readers are done with xs
         for (int i = threadIdx.x; i < n4; i += 256) ((float4_ *)xs)[i] = xp[i];
         __syncthreads();
-        float *yrow = y + (size_t)row * So * K + cg * 4;
+        T *yrow = y + (size_t)row * So * K + cg * 4;
         for (int ox = pl; ox < So; ox += PPP) {
             float xv[9];
 #pragma unroll
@@ -57,7 +77,7 @@ __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restric
                 for (int t = 0; t < 9; ++t) a = fmaf(xv[t], wr[t][c], a);
                 o[c] = a > 0.f ? a : 0.f;
             }
-            *(float4_ *)(yrow + (size_t)ox * K) = o;
+            store4(yrow + (size_t)ox * K, o);
         }
     }
 }
@@ -66,8 +86,8 @@ __global__ __launch_bounds__(256) void conv1ch_fwd_kernel(const float *__restric
 // forward; every lane keeps 10 x 4 partial sums in registers over all its pixels, the pixel slots of a wave are then
 // combined with wave shuffles and the four waves through 10 KiB of LDS: one partial vector per workgroup, reduced by
 // conv1ch_wgrad_reduce_kernel in a fixed order (deterministic).
-template <int K>
-__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+template <int K, typename T>
+__global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float *__restrict__ x, const T *__restrict__ dz,
                                                             float *__restrict__ partial, int S, int nrows, int rows_per_block)
 {
     constexpr int CG = K / 4, PPP = 256 / CG;
@@ -89,10 +109,10 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_kernel(const float *__restr
         __syncthreads();
         for (int i = threadIdx.x; i < n4; i += 256) ((float4_ *)xs)[i] = xp[i];
         __syncthreads();
-        const float *zrow = dz + (size_t)row * So * K + cg * 4;
+        const T *zrow = dz + (size_t)row * So * K + cg * 4;
 #pragma unroll 2
         for (int ox = pl; ox < So; ox += PPP) {
-            const float4_ g = *(const float4_ *)(zrow + (size_t)ox * K);
+            const float4_ g = load4(zrow + (size_t)ox * K);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -150,8 +170,8 @@ __global__ __launch_bounds__(256) void conv1ch_wgrad_reduce_kernel(const float *
 // 16 lanes x float4 cover a pixel's channels (C=64); partial dot products are combined with
 // wave shuffles, results staged in LDS so the two class planes are written coalesced.
 // ============================================================================================
-template <int C>
-__global__ __launch_bounds__(256) void head1x1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ bias, float *__restrict__ logits,
                                                           int B, int HW)
 {
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const float *__restric
         const size_t pix = base + lp;
         float s0 = 0.f, s1 = 0.f;
         if (pix < npix) {
-            const float4_ v = *(const float4_ *)(x + pix * C + cg * 4);
+            const float4_ v = load4(x + pix * C + cg * 4);
             s0 = v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
             s1 = v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
         }
@@ -191,9 +211,9 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const float *__restric
 
 // backward: dz[m][c] = (dl0[m]*w[0][c] + dl1[m]*w[1][c]) * (x[m][c] > 0);
 //           dw[k][c] = sum_m dl_k[m]*x[m][c];  db[k] = sum_m dl_k[m]   (partials per block)
-template <int C>
-__global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                          const float *__restrict__ dlogits, float *__restrict__ dz,
+template <int C, typename T>
+__global__ __launch_bounds__(256) void head1x1_bwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ dlogits, T *__restrict__ dz,
                                                           float *__restrict__ partial, int B, int HW)
 {
     constexpr int CG = C / 4, PPP = 256 / CG;
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float *__restric
     for (size_t pix = (size_t)blockIdx.x * PPP + pl; pix < npix; pix += (size_t)gridDim.x * PPP) {
         const size_t img = pix / HW, rem = pix - img * HW;
         const float d0 = dlogits[(img * 2) * HW + rem], d1 = dlogits[(img * 2 + 1) * HW + rem];
-        const float4_ v = *(const float4_ *)(x + pix * C + cg * 4);
+        const float4_ v = load4(x + pix * C + cg * 4);
         float4_ g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const float *__restric
             a0[c] = fmaf(d0, v[c], a0[c]);
             a1[c] = fmaf(d1, v[c], a1[c]);
         }
-        *(float4_ *)(dz + pix * C + cg * 4) = g;
+        store4(dz + pix * C + cg * 4, g);
         sb0 += d0; sb1 += d1;
     }
     __shared__ float red[PPP][2 * C + 2];
@@ -243,7 +263,8 @@ __global__ __launch_bounds__(256) void head1x1_bwd_reduce_kernel(const float *__
 // ============================================================================================
 // 2x2 max-pool, NHWC.                                                  network.py:133-151 (A3)
 // ============================================================================================
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                            int B, int H, int W, int C4)
 {
     const int Ho = H >> 1, Wo = W >> 1;
@@ -254,18 +275,19 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restri
         const int ox = (int)(pp % Wo); pp /= Wo;
         const int oy = (int)(pp % Ho);
         const int img = (int)(pp / Ho);
-        const float4_ *src = (const float4_ *)x + (((size_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c4;
-        const float4_ v00 = src[0], v01 = src[C4], v10 = src[(size_t)W * C4], v11 = src[(size_t)W * C4 + C4];
+        const T *src = x + ((((size_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c4) * 4;
+        const float4_ v00 = load4(src), v01 = load4(src + 4 * C4), v10 = load4(src + (size_t)W * C4 * 4), v11 = load4(src + ((size_t)W * C4 + C4) * 4);
         float4_ m;
 #pragma unroll
         for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaxf(v00[c], v01[c]), fmaxf(v10[c], v11[c]));
-        ((float4_ *)y)[e] = m;
+        store4(y + e * 4, m);             // a maximum of stored values: exact in either storage type
     }
 }
 
 // dpre = route(dy to the first maximum in row-major window order) * (pre > 0)
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restrict__ pre, const float *__restrict__ dy,
-                                                           float *__restrict__ dpre, int B, int H, int W, int C4)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T *__restrict__ pre, const T *__restrict__ dy,
+                                                           T *__restrict__ dpre, int B, int H, int W, int C4)
 {
     const int Ho = H >> 1, Wo = W >> 1;
     const size_t total = (size_t)B * Ho * Wo * C4;
@@ -275,11 +297,11 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
         const int ox = (int)(pp % Wo); pp /= Wo;
         const int oy = (int)(pp % Ho);
         const int img = (int)(pp / Ho);
-        const size_t o00 = (((size_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c4;
-        const size_t o01 = o00 + C4, o10 = o00 + (size_t)W * C4, o11 = o10 + C4;
-        const float4_ v00 = ((const float4_ *)pre)[o00], v01 = ((const float4_ *)pre)[o01];
-        const float4_ v10 = ((const float4_ *)pre)[o10], v11 = ((const float4_ *)pre)[o11];
-        const float4_ g = ((const float4_ *)dy)[e];
+        const size_t o00 = ((((size_t)img * H + 2 * oy) * W + 2 * ox) * C4 + c4) * 4;
+        const size_t o01 = o00 + 4 * (size_t)C4, o10 = o00 + (size_t)W * C4 * 4, o11 = o10 + 4 * (size_t)C4;
+        const float4_ v00 = load4(pre + o00), v01 = load4(pre + o01);
+        const float4_ v10 = load4(pre + o10), v11 = load4(pre + o11);
+        const float4_ g = load4(dy + e * 4);
         float4_ g00, g01, g10, g11;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -291,8 +313,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
             g00[c] = mi == 0 ? gv : 0.f; g01[c] = mi == 1 ? gv : 0.f;
             g10[c] = mi == 2 ? gv : 0.f; g11[c] = mi == 3 ? gv : 0.f;
         }
-        ((float4_ *)dpre)[o00] = g00; ((float4_ *)dpre)[o01] = g01;
-        ((float4_ *)dpre)[o10] = g10; ((float4_ *)dpre)[o11] = g11;
+        store4(dpre + o00, g00); store4(dpre + o01, g01);
+        store4(dpre + o10, g10); store4(dpre + o11, g11);
     }
 }
 
@@ -300,7 +322,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
 // Weight packers: reference layouts (OIHW / IOHW) -> igemm weight matrices [N][Kd].
 // ============================================================================================
 // conv fwd: wt[k][kd], kd = (c<C1 ? t*C1 + c : 9*C1 + t*C2 + (c-C1));  w[k][c][t]
-__global__ void pack_conv_fwd_kernel(const float *__restrict__ w, float *__restrict__ wt, int K, int C1, int C2)
+template <typename T>
+__global__ void pack_conv_fwd_kernel(const float *__restrict__ w, T *__restrict__ wt, int K, int C1, int C2)
 {
     const int C = C1 + C2;
     const size_t total = (size_t)K * C * 9;
@@ -310,40 +333,43 @@ __global__ void pack_conv_fwd_kernel(const float *__restrict__ w, float *__restr
         int c, t;
         if (kd < 9 * C1) { t = kd / C1; c = kd - t * C1; }
         else { const int r = kd - 9 * C1; t = r / C2; c = C1 + r - t * C2; }
-        wt[e] = w[((size_t)k * C + c) * 9 + t];
+        put1(wt + e, w[((size_t)k * C + c) * 9 + t]);
     }
 }
 // conv dgrad: wt[c][t'*K + k] = w[k][c][8 - t']
-__global__ void pack_conv_dgrad_kernel(const float *__restrict__ w, float *__restrict__ wt, int K, int C)
+template <typename T>
+__global__ void pack_conv_dgrad_kernel(const float *__restrict__ w, T *__restrict__ wt, int K, int C)
 {
     const size_t total = (size_t)K * C * 9;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int kd = (int)(e % (9 * K));
         const int c = (int)(e / (9 * K));
         const int t = kd / K, k = kd - t * K;
-        wt[e] = w[((size_t)k * C + c) * 9 + (8 - t)];
+        put1(wt + e, w[((size_t)k * C + c) * 9 + (8 - t)]);
     }
 }
 // up-conv fwd: wt[(ab)*Co + co][ci] = w[ci][co][ab]
-__global__ void pack_upconv_fwd_kernel(const float *__restrict__ w, float *__restrict__ wt, int Ci, int Co)
+template <typename T>
+__global__ void pack_upconv_fwd_kernel(const float *__restrict__ w, T *__restrict__ wt, int Ci, int Co)
 {
     const size_t total = (size_t)Ci * Co * 4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(e % Ci);
         const int n = (int)(e / Ci);
         const int ab = n / Co, co = n - ab * Co;
-        wt[e] = w[((size_t)ci * Co + co) * 4 + ab];
+        put1(wt + e, w[((size_t)ci * Co + co) * 4 + ab]);
     }
 }
 // up-conv dgrad: wt[ci][(ab)*Co + co] = w[ci][co][ab]
-__global__ void pack_upconv_dgrad_kernel(const float *__restrict__ w, float *__restrict__ wt, int Ci, int Co)
+template <typename T>
+__global__ void pack_upconv_dgrad_kernel(const float *__restrict__ w, T *__restrict__ wt, int Ci, int Co)
 {
     const size_t total = (size_t)Ci * Co * 4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int kd = (int)(e % (4 * Co));
         const int ci = (int)(e / (4 * Co));
         const int ab = kd / Co, co = kd - ab * Co;
-        wt[e] = w[((size_t)ci * Co + co) * 4 + ab];
+        put1(wt + e, w[((size_t)ci * Co + co) * 4 + ab]);
     }
 }
 
@@ -353,36 +379,34 @@ static inline int grid_for(size_t total, int per_block = 256, int cap = 8192)
     return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
 }
 
-int pack_conv_fwd(const float *w, float *wt, int K, int C1, int C2, hipStream_t st)
+// es = element size of the packed matrix: 4 (fp32) or 2 (bf16, arithmetic mode 2)
+#define PACK_LAUNCH(kern, total, ...)                                                                           \
+    do {                                                                                                         \
+        prof_begin(PK_ELEMWISE, #kern, st, 0.0, 0.0, (4.0 + es) * (double)(total));                               \
+        if (es == 2) hipLaunchKernelGGL(kern<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, w, (bf16_t *)wt, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern<float>, dim3(grid_for(total)), dim3(256), 0, st, w, (float *)wt, __VA_ARGS__);          \
+        prof_end(st);                                                                                            \
+        HIP_TRY(hipGetLastError());                                                                              \
+    } while (0)
+
+int pack_conv_fwd(const float *w, void *wt, int K, int C1, int C2, int es, hipStream_t st)
 {
-    prof_begin(PK_ELEMWISE, "pack_conv_fwd", st, 0.0, 0.0, 8.0 * (double)((size_t)K * (C1 + C2) * 9));
-    hipLaunchKernelGGL(pack_conv_fwd_kernel, dim3(grid_for((size_t)K * (C1 + C2) * 9)), dim3(256), 0, st, w, wt, K, C1, C2);
-    prof_end(st);
-    HIP_TRY(hipGetLastError());
+    PACK_LAUNCH(pack_conv_fwd_kernel, (size_t)K * (C1 + C2) * 9, K, C1, C2);
     return 0;
 }
-int pack_conv_dgrad(const float *w, float *wt, int K, int C, hipStream_t st)
+int pack_conv_dgrad(const float *w, void *wt, int K, int C, int es, hipStream_t st)
 {
-    prof_begin(PK_ELEMWISE, "pack_conv_dgrad", st, 0.0, 0.0, 8.0 * (double)((size_t)K * C * 9));
-    hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3(grid_for((size_t)K * C * 9)), dim3(256), 0, st, w, wt, K, C);
-    prof_end(st);
-    HIP_TRY(hipGetLastError());
+    PACK_LAUNCH(pack_conv_dgrad_kernel, (size_t)K * C * 9, K, C);
     return 0;
 }
-int pack_upconv_fwd(const float *w, float *wt, int Ci, int Co, hipStream_t st)
+int pack_upconv_fwd(const float *w, void *wt, int Ci, int Co, int es, hipStream_t st)
 {
-    prof_begin(PK_ELEMWISE, "pack_upconv_fwd", st, 0.0, 0.0, 8.0 * (double)((size_t)Ci * Co * 4));
-    hipLaunchKernelGGL(pack_upconv_fwd_kernel, dim3(grid_for((size_t)Ci * Co * 4)), dim3(256), 0, st, w, wt, Ci, Co);
-    prof_end(st);
-    HIP_TRY(hipGetLastError());
+    PACK_LAUNCH(pack_upconv_fwd_kernel, (size_t)Ci * Co * 4, Ci, Co);
     return 0;
 }
-int pack_upconv_dgrad(const float *w, float *wt, int Ci, int Co, hipStream_t st)
+int pack_upconv_dgrad(const float *w, void *wt, int Ci, int Co, int es, hipStream_t st)
 {
-    prof_begin(PK_ELEMWISE, "pack_upconv_dgrad", st, 0.0, 0.0, 8.0 * (double)((size_t)Ci * Co * 4));
-    hipLaunchKernelGGL(pack_upconv_dgrad_kernel, dim3(grid_for((size_t)Ci * Co * 4)), dim3(256), 0, st, w, wt, Ci, Co);
-    prof_end(st);
-    HIP_TRY(hipGetLastError());
+    PACK_LAUNCH(pack_upconv_dgrad_kernel, (size_t)Ci * Co * 4, Ci, Co);
     return 0;
 }
 
@@ -391,7 +415,8 @@ int pack_upconv_dgrad(const float *w, float *wt, int Ci, int Co, hipStream_t st)
 // (for the up-conv bias the caller passes M*4 rows of Cout).
 // ============================================================================================
 constexpr int BG_ROWS = 2048;     // rows per block in pass 1
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict__ dz, size_t M, int K,
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T *__restrict__ dz, size_t M, int K,
                                                         float *__restrict__ partial)
 {
     // thread -> (channel group of 4, row slot); K/4 groups, 256/(K/4) row slots (K/4 <= 256)
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float *__restrict_
     float4_ a = {0, 0, 0, 0};
     if (sl < slots)
         for (size_t r = r0 + sl; r < r1; r += slots) {
-            const float4_ v = *(const float4_ *)(dz + r * K + cg * 4);
+            const float4_ v = load4(dz + r * K + cg * 4);
             a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
         }
     __shared__ float4_ red[256];
@@ -429,12 +454,13 @@ __global__ void bias_grad_reduce_kernel(const float *__restrict__ partial, int n
     db[k] = (s0 + s1) + (s2 + s3);
 }
 size_t bias_grad_scratch_bytes(size_t M, int K) { return ((M + BG_ROWS - 1) / BG_ROWS) * K * sizeof(float); }
-int bias_grad(const float *dz, size_t M, int K, float *db, float *scratch, hipStream_t st)
+int bias_grad(const void *dz, size_t M, int K, float *db, float *scratch, int es, hipStream_t st)
 {
     ARG_CHECK(K % 4 == 0 && K / 4 <= 256, "bias_grad: K=%d unsupported", K);
     const int nb = (int)((M + BG_ROWS - 1) / BG_ROWS);
-    prof_begin(PK_ELEMWISE, "bias_grad", st, (double)M * K, 0.0, 4.0 * (double)M * K);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(256), 0, st, dz, M, K, scratch);
+    prof_begin(PK_ELEMWISE, "bias_grad", st, (double)M * K, 0.0, (double)es * M * K);
+    if (es == 2) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t *)dz, M, K, scratch);
+    else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(nb), dim3(256), 0, st, (const float *)dz, M, K, scratch);
     hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, scratch, nb, K, db);
     prof_end(st);
     HIP_TRY(hipGetLastError());
@@ -574,23 +600,22 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(const SgdTable tb, fl
     }
 }
 
-}  // namespace unet
-
-using namespace unet;
-
-extern "C" {
-
-int unet_conv1ch_fwd(const void *x, int B, int S, const void *w, const void *bias, int K, void *y, void *stream)
+// ---- launches of the kernels above; es = element size of the activation tensors (4: fp32, 2: bf16) -------------------------
+int conv1ch_fwd(const float *x, int B, int S, const float *w, const float *bias, int K, void *y, int es, hipStream_t st)
 {
     ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
     ARG_CHECK(S >= 3 && S % 4 == 0, "conv1ch: S=%d must be a multiple of 4", S);
-    hipStream_t st = (hipStream_t)stream;
     const int So = S - 2, nrows = B * So;
     const int grid = nrows < 2048 ? nrows : 2048;
     const size_t lds = (size_t)3 * S * sizeof(float);
-    prof_begin(PK_STENCIL, "conv1ch_fwd", st, 18.0 * nrows * So * K, 0.0, 4.0 * ((double)B * S * S + (double)nrows * So * K));
-    if (K == 64) hipLaunchKernelGGL(conv1ch_fwd_kernel<64>, dim3(grid), dim3(256), lds, st, (const float *)x, (const float *)w, (const float *)bias, (float *)y, S, nrows);
-    else hipLaunchKernelGGL(conv1ch_fwd_kernel<32>, dim3(grid), dim3(256), lds, st, (const float *)x, (const float *)w, (const float *)bias, (float *)y, S, nrows);
+    prof_begin(PK_STENCIL, "conv1ch_fwd", st, 18.0 * nrows * So * K, 0.0, 4.0 * B * S * S + (double)es * nrows * So * K);
+    if (es == 2) {
+        if (K == 64) hipLaunchKernelGGL((conv1ch_fwd_kernel<64, bf16_t>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t *)y, S, nrows);
+        else hipLaunchKernelGGL((conv1ch_fwd_kernel<32, bf16_t>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t *)y, S, nrows);
+    } else {
+        if (K == 64) hipLaunchKernelGGL((conv1ch_fwd_kernel<64, float>), dim3(grid), dim3(256), lds, st, x, w, bias, (float *)y, S, nrows);
+        else hipLaunchKernelGGL((conv1ch_fwd_kernel<32, float>), dim3(grid), dim3(256), lds, st, x, w, bias, (float *)y, S, nrows);
+    }
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -603,80 +628,127 @@ static void conv1ch_bwd_split(int B, int S, int &rpb, int &nb)
     rpb = cdiv(nrows, 1024);
     nb = cdiv(nrows, rpb);
 }
-size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K) { int rpb, nb; conv1ch_bwd_split(B, S, rpb, nb); return (size_t)nb * 10 * K * sizeof(float); }
-int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *dw, void *db, void *scratch, void *stream)
+int conv1ch_bwd(const float *x, int B, int S, int K, const void *dz, float *dw, float *db, float *scratch, int es, hipStream_t st)
 {
     ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
     ARG_CHECK(S >= 3 && S % 4 == 0, "conv1ch: S=%d must be a multiple of 4", S);
     int rpb, nb;
     conv1ch_bwd_split(B, S, rpb, nb);
-    hipStream_t st = (hipStream_t)stream;
     const int So = S - 2, nrows = B * So;
     size_t lds = (size_t)3 * S * sizeof(float);
     if (lds < (size_t)40 * K * sizeof(float)) lds = (size_t)40 * K * sizeof(float);
-    prof_begin(PK_STENCIL, "conv1ch_wgrad", st, 20.0 * nrows * So * K, 0.0, 4.0 * ((double)B * S * S + (double)nrows * So * K));
-    if (K == 64) hipLaunchKernelGGL(conv1ch_wgrad_kernel<64>, dim3(nb), dim3(256), lds, st, (const float *)x, (const float *)dz, (float *)scratch, S, nrows, rpb);
-    else hipLaunchKernelGGL(conv1ch_wgrad_kernel<32>, dim3(nb), dim3(256), lds, st, (const float *)x, (const float *)dz, (float *)scratch, S, nrows, rpb);
-    hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(cdiv(10 * K, 4)), dim3(256), 0, st, (const float *)scratch, nb, K, (float *)dw, (float *)db);
+    prof_begin(PK_STENCIL, "conv1ch_wgrad", st, 20.0 * nrows * So * K, 0.0, 4.0 * B * S * S + (double)es * nrows * So * K);
+    if (es == 2) {
+        if (K == 64) hipLaunchKernelGGL((conv1ch_wgrad_kernel<64, bf16_t>), dim3(nb), dim3(256), lds, st, x, (const bf16_t *)dz, scratch, S, nrows, rpb);
+        else hipLaunchKernelGGL((conv1ch_wgrad_kernel<32, bf16_t>), dim3(nb), dim3(256), lds, st, x, (const bf16_t *)dz, scratch, S, nrows, rpb);
+    } else {
+        if (K == 64) hipLaunchKernelGGL((conv1ch_wgrad_kernel<64, float>), dim3(nb), dim3(256), lds, st, x, (const float *)dz, scratch, S, nrows, rpb);
+        else hipLaunchKernelGGL((conv1ch_wgrad_kernel<32, float>), dim3(nb), dim3(256), lds, st, x, (const float *)dz, scratch, S, nrows, rpb);
+    }
+    hipLaunchKernelGGL(conv1ch_wgrad_reduce_kernel, dim3(cdiv(10 * K, 4)), dim3(256), 0, st, (const float *)scratch, nb, K, dw, db);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int unet_head1x1_fwd(const void *x, int B, int H, int W, int C, const void *w, const void *bias, void *logits, void *stream)
+int head1x1_fwd(const void *x, int B, int H, int W, int C, const float *w, const float *bias, float *logits, int es, hipStream_t st)
 {
     ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
-    hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)B * H * W;
     const int ppb = (256 / (C / 4)) * 16;
     const int grid = (int)((npix + ppb - 1) / ppb);
-    prof_begin(PK_ELEMWISE, "head1x1_fwd", st, 4.0 * npix * C, 0.0, 4.0 * npix * (C + 2));
-    if (C == 64) hipLaunchKernelGGL(head1x1_fwd_kernel<64>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
-    else hipLaunchKernelGGL(head1x1_fwd_kernel<32>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)bias, (float *)logits, B, H * W);
+    prof_begin(PK_ELEMWISE, "head1x1_fwd", st, 4.0 * npix * C, 0.0, (double)npix * (es * C + 8));
+    if (es == 2) {
+        if (C == 64) hipLaunchKernelGGL((head1x1_fwd_kernel<64, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t *)x, w, bias, logits, B, H * W);
+        else hipLaunchKernelGGL((head1x1_fwd_kernel<32, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t *)x, w, bias, logits, B, H * W);
+    } else {
+        if (C == 64) hipLaunchKernelGGL((head1x1_fwd_kernel<64, float>), dim3(grid), dim3(256), 0, st, (const float *)x, w, bias, logits, B, H * W);
+        else hipLaunchKernelGGL((head1x1_fwd_kernel<32, float>), dim3(grid), dim3(256), 0, st, (const float *)x, w, bias, logits, B, H * W);
+    }
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 512); }
-size_t unet_head1x1_bwd_scratch_bytes(int B, int H, int W, int C) { return (size_t)head_bwd_blocks(B, H, W) * (2 * C + 2) * sizeof(float); }
-int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, const void *dlogits, void *dz,
-                     void *dw, void *db, void *scratch, void *stream)
+int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, void *dz, float *dw, float *db,
+                float *scratch, int es, hipStream_t st)
 {
     ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
     const int nb = head_bwd_blocks(B, H, W);
-    hipStream_t st = (hipStream_t)stream;
     const double npix = (double)B * H * W;
-    prof_begin(PK_ELEMWISE, "head1x1_bwd", st, 8.0 * npix * C, 0.0, 4.0 * npix * (2 * C + 2));
-    if (C == 64) hipLaunchKernelGGL(head1x1_bwd_kernel<64>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
-    else hipLaunchKernelGGL(head1x1_bwd_kernel<32>, dim3(nb), dim3(256), 0, st, (const float *)x, (const float *)w, (const float *)dlogits, (float *)dz, (float *)scratch, B, H * W);
-    hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 4)), dim3(256), 0, st, (const float *)scratch, nb, C, (float *)dw, (float *)db);
+    prof_begin(PK_ELEMWISE, "head1x1_bwd", st, 8.0 * npix * C, 0.0, npix * (2.0 * es * C + 8));
+    if (es == 2) {
+        if (C == 64) hipLaunchKernelGGL((head1x1_bwd_kernel<64, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)x, w, dlogits, (bf16_t *)dz, scratch, B, H * W);
+        else hipLaunchKernelGGL((head1x1_bwd_kernel<32, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)x, w, dlogits, (bf16_t *)dz, scratch, B, H * W);
+    } else {
+        if (C == 64) hipLaunchKernelGGL((head1x1_bwd_kernel<64, float>), dim3(nb), dim3(256), 0, st, (const float *)x, w, dlogits, (float *)dz, scratch, B, H * W);
+        else hipLaunchKernelGGL((head1x1_bwd_kernel<32, float>), dim3(nb), dim3(256), 0, st, (const float *)x, w, dlogits, (float *)dz, scratch, B, H * W);
+    }
+    hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 4)), dim3(256), 0, st, (const float *)scratch, nb, C, dw, db);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int unet_maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, void *stream)
+int maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, int es, hipStream_t st)
 {
     ARG_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: H,W must be even and C a multiple of 4");
-    hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    prof_begin(PK_ELEMWISE, "maxpool2_fwd", st, 0.0, 0.0, 16.0 * (double)total * 5.0);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const float *)x, (float *)y, B, H, W, C / 4);
+    prof_begin(PK_ELEMWISE, "maxpool2_fwd", st, 0.0, 0.0, 4.0 * es * (double)total * 5.0);
+    if (es == 2) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const bf16_t *)x, (bf16_t *)y, B, H, W, C / 4);
+    else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const float *)x, (float *)y, B, H, W, C / 4);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int unet_maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, void *stream)
+int maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, int es, hipStream_t st)
 {
     ARG_CHECK(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: H,W must be even and C a multiple of 4");
-    hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    prof_begin(PK_ELEMWISE, "maxpool2_bwd", st, 0.0, 0.0, 16.0 * (double)total * 9.0);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const float *)pre, (const float *)dy, (float *)dpre, B, H, W, C / 4);
+    prof_begin(PK_ELEMWISE, "maxpool2_bwd", st, 0.0, 0.0, 4.0 * es * (double)total * 9.0);
+    if (es == 2) hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const bf16_t *)pre, (const bf16_t *)dy, (bf16_t *)dpre, B, H, W, C / 4);
+    else hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (const float *)pre, (const float *)dy, (float *)dpre, B, H, W, C / 4);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+}  // namespace unet
+
+using namespace unet;
+
+extern "C" {
+
+// element size of the activation tensors the per-op entry points take: bf16 in arithmetic mode 2, else fp32
+static int op_es() { return get_math_mode() == 2 ? 2 : 4; }
+
+int unet_conv1ch_fwd(const void *x, int B, int S, const void *w, const void *bias, int K, void *y, void *stream)
+{
+    return conv1ch_fwd((const float *)x, B, S, (const float *)w, (const float *)bias, K, y, op_es(), (hipStream_t)stream);
+}
+size_t unet_conv1ch_bwd_scratch_bytes(int B, int S, int K) { int rpb, nb; conv1ch_bwd_split(B, S, rpb, nb); return (size_t)nb * 10 * K * sizeof(float); }
+int unet_conv1ch_bwd(const void *x, int B, int S, int K, const void *dz, void *dw, void *db, void *scratch, void *stream)
+{
+    return conv1ch_bwd((const float *)x, B, S, K, dz, (float *)dw, (float *)db, (float *)scratch, op_es(), (hipStream_t)stream);
+}
+int unet_head1x1_fwd(const void *x, int B, int H, int W, int C, const void *w, const void *bias, void *logits, void *stream)
+{
+    return head1x1_fwd(x, B, H, W, C, (const float *)w, (const float *)bias, (float *)logits, op_es(), (hipStream_t)stream);
+}
+size_t unet_head1x1_bwd_scratch_bytes(int B, int H, int W, int C) { return (size_t)head_bwd_blocks(B, H, W) * (2 * C + 2) * sizeof(float); }
+int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, const void *dlogits, void *dz,
+                     void *dw, void *db, void *scratch, void *stream)
+{
+    return head1x1_bwd(x, B, H, W, C, (const float *)w, (const float *)dlogits, dz, (float *)dw, (float *)db, (float *)scratch, op_es(), (hipStream_t)stream);
+}
+int unet_maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, void *stream)
+{
+    return maxpool2_fwd(x, y, B, H, W, C, op_es(), (hipStream_t)stream);
+}
+int unet_maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, void *stream)
+{
+    return maxpool2_bwd(pre, dy, dpre, B, H, W, C, op_es(), (hipStream_t)stream);
 }
 
 size_t unet_bce_scratch_bytes(size_t numel) { return ((numel + BCE_PER_BLOCK - 1) / BCE_PER_BLOCK) * sizeof(double); }

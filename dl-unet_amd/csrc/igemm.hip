@@ -23,7 +23,8 @@
 
 namespace unet {
 
-int launch_igemmx(const IgemmP &p, bool pad, int nsplit, hipStream_t st);
+int launch_igemmx(const IgemmP &p, bool pad, hipStream_t st);
+int launch_igemmb(IgemmP p, bool pad, hipStream_t st);
 int launch_wino(const IgemmP &p, const float *U, hipStream_t st);
 
 // 0 = fp32 MFMA, direct (every product of the correlation: an exact fmaf chain), 1 = bf16x3 split (fp32-class accuracy on
@@ -291,6 +292,7 @@ int launch_igemm(IgemmP p, hipStream_t st)
     ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0xFFFFFFFFull, "igemm: destination exceeds 32-bit element offsets");
     for (int i = 0; i < p.nsrc; ++i)
         ARG_CHECK((size_t)p.NB * p.src[i].H * p.src[i].W * p.src[i].C < 0x7FFFFFFFull, "igemm: source exceeds 31-bit element offsets");
+    ARG_CHECK(!p.pool_dst || (p.math == 3 && p.wino_u), "igemm: the fused max-pool exists only in the Winograd epilogue");
     p.zeros = zero_page();
     if (!p.zeros) return -2;
     p.d_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
@@ -300,8 +302,8 @@ int launch_igemm(IgemmP p, hipStream_t st)
         ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemm: destination exceeds 31-bit element offsets");
         return launch_wino(p, p.wino_u, st);
     }
-    if (p.math == 1) return launch_igemmx(p, pad, 3, st);
-    if (p.math == 2) return launch_igemmx(p, pad, 1, st);
+    if (p.math == 1) return launch_igemmx(p, pad, st);
+    if (p.math == 2) return launch_igemmb(p, pad, st);          // bf16 tensors (igemmb.hip)
     ARG_CHECK((size_t)p.NB * p.DH * p.DW * p.DC < 0x7FFFFFFFull, "igemm: destination exceeds 31-bit element offsets");
     // buffer-descriptor LDS-DMA needs sources and weights below 2 GiB
     bool buf = g_lds_dma != 0;

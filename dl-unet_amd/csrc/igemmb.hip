@@ -293,7 +293,7 @@ static int launch_cfgb(const IgemmP &p, hipStream_t st)
     q.ntiles = cdiv(p.Nn, BN);
     char tag[96];
     snprintf(tag, sizeof(tag), "igemmb<%d;%d;%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
-    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * q.mtiles * BM * (double)q.ntiles * BN * p.Kd, igemm_alg_bytes(p));
+    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * q.mtiles * BM * (double)q.ntiles * BN * p.Kd, igemm_alg_bytes(p) / 2.0);   // every tensor is 2 B/element
     hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());

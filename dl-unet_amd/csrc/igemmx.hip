@@ -1,11 +1,11 @@
-// igemmx.hip — the implicit GEMM of igemm.hip on the bf16 matrix cores, with fp32 tensors in HBM.
+// igemmx.hip — the implicit GEMM of igemm.hip on the bf16 matrix cores, with fp32 tensors in HBM (arithmetic mode 1).
 //
-//   NSPLIT = 3  "bf16x3": every fp32 operand is split in registers into hi = bf16(x) and lo = bf16(x - hi);
+//   "bf16x3" (NSPLIT = 3): every fp32 operand is split in registers into hi = bf16(x) and lo = bf16(x - hi);
 //               a*b ~= hi*hi + hi*lo + lo*hi with fp32 accumulation (the lo*lo term, 2^-16 relative, is
 //               dropped).  Products carry ~16 mantissa bits instead of 24; measured end-to-end error of the
 //               logits stays at the 1e-5 level (tests), 100x inside the path's 1e-3 tolerance.  Opt-in
 //               (unet_set_math(1)): the default path is the exact-fp32 MFMA of igemm.hip.
-//   NSPLIT = 1  "bf16": hi only — bf16 compute with fp32 storage and accumulation (BASELINE config #3).
+//   (bf16 tensors in HBM — BASELINE config #3, mode 2 — are igemmb.hip: no conversion, LDS-DMA staging.)
 //
 // v_mfma_f32_32x32x16_bf16 issues in 32 cycles for K=16 against 8 x 64 cycles of the fp32 MFMA: 5.3x
 // (bf16x3) or 16x (bf16) less matrix-pipe time, so this kernel is bound by staging, not by the MFMA.
@@ -218,14 +218,10 @@ static int launch_cfgx(const IgemmP &p, hipStream_t st)
     return 0;
 }
 
-int launch_igemmx(const IgemmP &p, bool pad, int nsplit, hipStream_t st)
+int launch_igemmx(const IgemmP &p, bool pad, hipStream_t st)
 {
-    if (nsplit == 3) {
-        if (p.Nn % 128 == 0) return pad ? launch_cfgx<128, 128, true, 3>(p, st) : launch_cfgx<128, 128, false, 3>(p, st);
-        return pad ? launch_cfgx<256, 64, true, 3>(p, st) : launch_cfgx<256, 64, false, 3>(p, st);
-    }
-    if (p.Nn % 128 == 0) return pad ? launch_cfgx<128, 128, true, 1>(p, st) : launch_cfgx<128, 128, false, 1>(p, st);
-    return pad ? launch_cfgx<256, 64, true, 1>(p, st) : launch_cfgx<256, 64, false, 1>(p, st);
+    if (p.Nn % 128 == 0) return pad ? launch_cfgx<128, 128, true, 3>(p, st) : launch_cfgx<128, 128, false, 3>(p, st);
+    return pad ? launch_cfgx<256, 64, true, 3>(p, st) : launch_cfgx<256, 64, false, 3>(p, st);
 }
 
 }  // namespace unet

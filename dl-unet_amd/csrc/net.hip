@@ -96,6 +96,19 @@ int unet_handle_device(const unet_handle *h) { return h->device; }
 
 namespace unet {
 
+// Arithmetic mode of the C-ABI call this thread is in; the descriptor builders copy it into every launch descriptor
+// (handle entry points: the plan's mode; per-op entry points: the process default).
+static thread_local int t_math = 3;
+static thread_local int t_es = 4;            // element size of activations / activation gradients / packed filters: 2 (bf16) in mode 2
+struct MathScope {
+    int prev;
+    explicit MathScope(int m) : prev(t_math) { t_math = m; t_es = m == 2 ? 2 : 4; }
+    ~MathScope() { t_math = prev; t_es = prev == 2 ? 2 : 4; }
+};
+// pointer arithmetic on tensors whose element size depends on the mode (the descriptors carry them as float*)
+static inline const float *adv(const float *p, size_t elems) { return (const float *)((const char *)p + elems * t_es); }
+static inline float *adv(float *p, size_t elems) { return (float *)((char *)p + elems * t_es); }
+
 static size_t layer_numel(int base, int layer, bool bias)
 {
     const int c[5] = {base, base * 2, base * 4, base * 8, base * 16};
@@ -148,7 +161,7 @@ struct WLayer {
     {
         if (packed) return 0;
         packed = true;
-        return dgrad ? pack_conv_dgrad(w, wt, O, I, st) : pack_conv_fwd(w, wt, O, C1, C2, st);
+        return dgrad ? pack_conv_dgrad(w, wt, O, I, t_es, st) : pack_conv_fwd(w, wt, O, C1, C2, t_es, st);
     }
 };
 static WLayer wl_fwd(const float *w, int K, int C1, int C2, float *wt) { return WLayer{w, K, C1 + C2, false, wt, C1, C2}; }
@@ -176,15 +189,6 @@ static int check_size(int S)
     }
     return 0;
 }
-
-// Arithmetic mode of the C-ABI call this thread is in; the descriptor builders copy it into every launch descriptor
-// (handle entry points: the plan's mode; per-op entry points: the process default).
-static thread_local int t_math = 3;
-struct MathScope {
-    int prev;
-    explicit MathScope(int m) : prev(t_math) { t_math = m; }
-    ~MathScope() { t_math = prev; }
-};
 
 static const char *const LAYER_NAME[UNET_N_LAYERS] = {
     "conv11c", "conv12c", "conv21c", "conv22c", "conv31c", "conv32c", "conv41c", "conv42c", "conv51c", "conv52c",
@@ -235,7 +239,7 @@ static int conv_fwd_launch(const float *x1, int H1, int C1, int pad1, const floa
         return launch_igemm(p, st);
     }
     const int ldw = 9 * (C1 + C2);
-    IgemmP a = conv_fwd_desc(x2, H, H, C2, 0, nullptr, 0, B, H, H, wt + 9 * C1, bias, K, relu, y);
+    IgemmP a = conv_fwd_desc(x2, H, H, C2, 0, nullptr, 0, B, H, H, adv(wt, 9 * C1), bias, K, relu, y);
     a.ldw = ldw;
     if (relu) { a.rw0 = w0; a.rw1 = w1; }
     if ((rc = with_wino(a, wu, L, 0, C1, st))) return rc;
@@ -321,8 +325,12 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
         pl.ed1[l] = pl.eu[l] - 2; pl.ed2[l] = pl.eu[l] - 4; d = pl.ed2[l];
     }
     pl.So = d;
+    if (math == 2 && base % 64 != 0) { set_error("arithmetic mode 2 (bf16 tensors) needs base_ch %% 64 == 0 (got %d)", base); return UNET_E_UNSUPPORTED; }
+    // element size of activations, their gradients and the packed filters: bf16 in mode 2, else fp32
+    const size_t es = math == 2 ? 2 : 4;
     size_t off = 0;
-    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    auto take_b = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    auto take = [&](size_t elems) { return take_b(elems * es); };
     auto sq = [&](int e, int c) { return (size_t)B * e * e * c; };
     for (int l = 0; l < 5; ++l) { pl.a1[l] = take(sq(pl.ea1[l], pl.ch[l])); pl.a2[l] = take(sq(pl.ea2[l], pl.ch[l])); }
     for (int l = 0; l < 4; ++l) {
@@ -330,11 +338,11 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
         pl.d1[l] = take(sq(pl.ed1[l], pl.ch[l])); pl.d2[l] = take(sq(pl.ed2[l], pl.ch[l]));
     }
     for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wt_fwd[i] = take(layer_numel(base, i, false));
-    for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wu_fwd[i] = take(layer_wino_floats(base, i));
+    for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wu_fwd[i] = take_b(math == 3 ? layer_wino_floats(base, i) * 4 : 0);
     if (training) {
-        pl.xin = take((size_t)B * S * S);
+        pl.xin = take_b((size_t)B * S * S * 4);
         for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wt_bwd[i] = take(layer_numel(base, i, false));
-        for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wu_bwd[i] = take(layer_wino_floats(base, i));
+        for (int i = 0; i < UNET_N_LAYERS; ++i) pl.wu_bwd[i] = take_b(math == 3 ? layer_wino_floats(base, i) * 4 : 0);
         for (int l = 0; l < 5; ++l) { pl.g_a1[l] = take(sq(pl.ea1[l], pl.ch[l])); pl.g_a2[l] = take(sq(pl.ea2[l], pl.ch[l])); }
         for (int l = 0; l < 4; ++l) {
             pl.g_t[l] = take(sq(pl.et[l], pl.ch[l])); pl.g_ts[l] = take(sq(pl.et[l], pl.ch[l]));
@@ -357,7 +365,7 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
             }
         }
         pl.slab_bytes = need;
-        pl.slab = take(need / sizeof(float));
+        pl.slab = take_b(need);
         // small scratch: bias-grad partials, conv11c / head partials
         size_t sm = 0;
         auto upds = [&](size_t n) { if (n > sm) sm = n; };
@@ -366,7 +374,7 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
         upds(unet_conv1ch_bwd_scratch_bytes(B, S, base));
         upds(unet_head1x1_bwd_scratch_bytes(B, pl.So, pl.So, base));
         pl.small_bytes = sm;
-        pl.small = take(sm / sizeof(float) + 1);
+        pl.small = take_b(sm + 4);
     }
     pl.total = off;
     return 0;
@@ -499,14 +507,14 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
     // (the 3x3 layers' weights are packed lazily, only if a launch of the layer takes the implicit-GEMM path: with_wino)
     for (int l = 0; l < 4; ++l) {
         RowScope rs(UP_L[l], "fwd");
-        if ((rc = pack_upconv_fwd(PARAM(2 * UP_L[l]), WS(pl.wt_fwd[UP_L[l]]), ch[l + 1], ch[l], st))) return rc;
+        if ((rc = pack_upconv_fwd(PARAM(2 * UP_L[l]), WS(pl.wt_fwd[UP_L[l]]), ch[l + 1], ch[l], t_es, st))) return rc;
     }
 
     // encoder (network.py:131-156); the input is kept for conv11c's weight gradient
     {
         RowScope rs(C11C, "fwd");
         if (training) HIP_TRY(hipMemcpyAsync(WS(pl.xin), x, (size_t)B * S * S * sizeof(float), hipMemcpyDeviceToDevice, st));
-        if ((rc = unet_conv1ch_fwd(x, B, S, PARAM(0), PARAM(1), ch[0], WS(pl.a1[0]), stream))) return rc;
+        if ((rc = conv1ch_fwd((const float *)x, B, S, PARAM(0), PARAM(1), ch[0], WS(pl.a1[0]), t_es, st))) return rc;
     }
     for (int l = 0; l < 5; ++l) {
         if (l > 0) {
@@ -531,7 +539,7 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
         if (l < 4 && !pool_fused) {
             char nm[40]; snprintf(nm, sizeof(nm), "pool%d.fwd", l + 1);
             ProfScope ps(nm);
-            if ((rc = unet_maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], stream))) return rc;
+            if ((rc = maxpool2_fwd(WS(pl.a2[l]), WS(pl.t[l]), B, pl.ea2[l], pl.ea2[l], ch[l], t_es, st))) return rc;
         }
     }
     // decoder (network.py:159-188): up-conv, virtual zero-pad-concat, two convs
@@ -568,10 +576,16 @@ int unet_forward(unet_handle *h, const void *const *params, const void *x, void 
     }
     {
         RowScope rs(FINAL, "fwd");
-        if ((rc = unet_head1x1_fwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), PARAM(2 * FINAL + 1), logits, stream))) return rc;
+        if ((rc = head1x1_fwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), PARAM(2 * FINAL + 1), (float *)logits, t_es, st))) return rc;
     }
     if (training) h->remember(workspace, pl);
     return 0;
+}
+
+int unet_activation_bytes(const unet_handle *h)
+{
+    if (!h) return 0;
+    return handle_math(h) == 2 ? 2 : 4;
 }
 
 /* Debug/introspection: byte offset and element count of a named workspace buffer, e.g. "a1_0",
@@ -663,7 +677,7 @@ static int pool_backward(const Plan &pl, void *workspace, int l, void *stream)
 {
     char nm[40]; snprintf(nm, sizeof(nm), "pool%d.bwd", l + 1);
     ProfScope ps(nm);
-    return unet_maxpool2_bwd(WS(pl.a2[l]), WS(pl.g_t[l]), WS(pl.g_a2[l]), pl.B, pl.ea2[l], pl.ea2[l], pl.ch[l], stream);
+    return maxpool2_bwd(WS(pl.a2[l]), WS(pl.g_t[l]), WS(pl.g_a2[l]), pl.B, pl.ea2[l], pl.ea2[l], pl.ch[l], t_es, (hipStream_t)stream);
 }
 
 int unet_backward_stage(unet_handle *h, int stage, const void *const *params, const void *dlogits, void *const *grads,
@@ -691,8 +705,8 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             ARG_CHECK(dlogits, "unet_backward: null dlogits");
             // finalconv backward, fused with the ReLU backward of conv12e -> dz of conv12e
             RowScope rs(FINAL, "bwd");
-            if ((rc = unet_head1x1_bwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), dlogits, WS(pl.g_d2[0]),
-                                       GRAD(2 * FINAL), GRAD(2 * FINAL + 1), WS(pl.small), stream))) return rc;
+            if ((rc = head1x1_bwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), (const float *)dlogits, WS(pl.g_d2[0]),
+                                  GRAD(2 * FINAL), GRAD(2 * FINAL + 1), WS(pl.small), t_es, st))) return rc;
         }
         // conv_l2e: input d1[l] (ReLU output of conv_l1e)
         if ((rc = conv_backward(pl, workspace, st, params, grads, C2E_L[l], WS(pl.d1[l]), pl.ed1[l], ch[l], WS(pl.g_d2[l]), pl.ed2[l], ch[l],
@@ -707,7 +721,7 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             if ((rc = with_wino(ds, WS(pl.wu_bwd[lay]), Ld, 0, 0, st))) return rc;
             if ((rc = launch_igemm(ds, st))) return rc;
             IgemmP du = conv_dgrad_desc(WS(pl.g_d1[l]), pl.ed1[l], pl.ed1[l], ch[l], B, pl.eu[l], 0,
-                                        WS(pl.wt_bwd[lay]) + (size_t)ch[l] * 9 * ch[l], ch[l], WS(pl.g_u[l]), nullptr, nullptr);
+                                        adv(WS(pl.wt_bwd[lay]), (size_t)ch[l] * 9 * ch[l]), ch[l], WS(pl.g_u[l]), nullptr, nullptr);
             if ((rc = with_wino(du, WS(pl.wu_bwd[lay]) + wino_u_floats(ch[l], ch[l]), Ld, ch[l], 0, st))) return rc;
             if ((rc = launch_igemm(du, st))) return rc;
         }
@@ -728,7 +742,7 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             float *dzin = l == 3 ? WS(pl.g_a2[4]) : WS(pl.g_d2[l + 1]);
             {
                 RowScope rs(ul, "dgrad");
-                if ((rc = pack_upconv_dgrad(PARAM(2 * ul), WS(pl.wt_bwd[ul]), ch[l + 1], ch[l], st))) return rc;
+                if ((rc = pack_upconv_dgrad(PARAM(2 * ul), WS(pl.wt_bwd[ul]), ch[l + 1], ch[l], t_es, st))) return rc;
                 IgemmP d{};
                 d.nsrc = 1; d.src[0] = GSrc{WS(pl.g_u[l]), pl.eu[l], pl.eu[l], ch[l], 0, ch[l], 0};
                 d.wt = WS(pl.wt_bwd[ul]); d.Kd = 4 * ch[l];
@@ -761,7 +775,7 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
         if (l == 0) {
             // conv11c: weight/bias gradient only (A1 needs no dgrad)
             RowScope rs(C11C, "wgrad");
-            return unet_conv1ch_bwd(WS(pl.xin), B, pl.S, ch[0], WS(pl.g_a1[0]), GRAD(0), GRAD(1), WS(pl.small), stream);
+            return conv1ch_bwd(WS(pl.xin), B, pl.S, ch[0], WS(pl.g_a1[0]), GRAD(0), GRAD(1), WS(pl.small), t_es, st);
         }
         if ((rc = conv_backward(pl, workspace, st, params, grads, 2 * l, WS(pl.t[l - 1]), pl.ein[l], ch[l - 1], WS(pl.g_a1[l]), pl.ea1[l], ch[l],
                                 WS(pl.g_t[l - 1]), nullptr, WS(pl.g_ts[l - 1])))) return rc;
@@ -858,7 +872,7 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
             if ((rc = launch_igemm(d, st))) return rc;
         }
         if (dx2 && x2) {
-            IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H, 0, wt + (size_t)C1 * 9 * K, C2, (float *)dx2, (const float *)mask2, nullptr);
+            IgemmP d = conv_dgrad_desc((const float *)dz, Ho, Ho, K, B, H, 0, adv(wt, (size_t)C1 * 9 * K), C2, (float *)dx2, (const float *)mask2, nullptr);
             if ((rc = with_wino(d, wu + wino_u_floats(K, C1), L, C1, 0, st))) return rc;
             if ((rc = launch_igemm(d, st))) return rc;
         }
@@ -877,7 +891,7 @@ int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
             db_done = db != nullptr;
         }
     }
-    if (db && !db_done && (rc = bias_grad((const float *)dz, (size_t)B * Ho * Ho, K, (float *)db, small, st))) return rc;
+    if (db && !db_done && (rc = bias_grad(dz, (size_t)B * Ho * Ho, K, (float *)db, small, t_es, st))) return rc;
     return 0;
 }
 
@@ -895,7 +909,7 @@ int unet_upconv2_fwd(const void *x, int B, int H, int W, int Ci, const void *w_i
     MathScope ms(get_math_mode());
     ProfScope ps("op.upconv2_fwd");
     hipStream_t st = (hipStream_t)stream;
-    int rc = pack_upconv_fwd((const float *)w_iohw, (float *)scratch, Ci, Co, st);
+    int rc = pack_upconv_fwd((const float *)w_iohw, scratch, Ci, Co, t_es, st);
     if (rc) return rc;
     IgemmP u{};
     u.nsrc = 1; u.src[0] = GSrc{(const float *)x, H, W, Ci, 0, Ci, 0};
@@ -923,7 +937,7 @@ int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_i
     float *small = (float *)((char *)scratch + wt_bytes + slab_bytes);
     int rc;
     if (dx) {
-        if ((rc = pack_upconv_dgrad((const float *)w_iohw, wt, Ci, Co, st))) return rc;
+        if ((rc = pack_upconv_dgrad((const float *)w_iohw, wt, Ci, Co, t_es, st))) return rc;
         IgemmP d{};
         d.nsrc = 1; d.src[0] = GSrc{(const float *)dy, 2 * H, 2 * W, Co, 0, Co, 0};
         d.wt = wt; d.Kd = 4 * Co;
@@ -937,7 +951,7 @@ int unet_upconv2_bwd(const void *x, int B, int H, int W, int Ci, const void *w_i
     if (dw) {
         WgradP w = upconv_wgrad_desc((const float *)x, H, Ci, (const float *)dy, Co, B, (float *)dw, slab, slab_bytes, (float *)db);
         if ((rc = launch_wgrad(w, st))) return rc;
-    } else if (db && (rc = bias_grad((const float *)dy, (size_t)B * 4 * H * W, Co, (float *)db, small, st))) return rc;
+    } else if (db && (rc = bias_grad(dy, (size_t)B * 4 * H * W, Co, (float *)db, small, t_es, st))) return rc;
     return 0;
 }
 

@@ -37,6 +37,7 @@ constexpr int PWMAX = 32;     // pixels per strip (MFMA K = pixel pairs)
 struct WgradK {               // kernel-side copy with the derived decomposition
     WgradP p;
     int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
+    int xbytes, ybytes;                // bf16 kernel: buffer-descriptor sizes of X and Y
     int nparts, ngroups;               // pixel partitions, and workgroups per channel tile that share them
     size_t pstride;                    // floats per partition in the slab: T*Ci*Cj weights + Cj bias partials
 };
@@ -54,7 +55,7 @@ struct WgradGeom {
     static_assert(TY + S <= RING, "ring too small");
 };
 
-template <int TY, int TX, int S, int NSPLIT>   // NSPLIT 0: exact fp32 MFMA; 1: bf16; 3: bf16x3 split (see igemmx.hip)
+template <int TY, int TX, int S, int NSPLIT>   // NSPLIT 0: exact fp32 MFMA; 3: bf16x3 split of fp32 operands (see igemmx.hip)
 __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void wgrad_f32_kernel(const WgradK k)
 {
     using G = WgradGeom<TY, TX, S>;
@@ -234,6 +235,186 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
             dst4[(t * 4 + rq) * 64] = f32x4{acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 tensors (arithmetic mode 2): X and Y are bf16 NHWC, the MFMA is v_mfma_f32_32x32x16_bf16 with K = 16 pixels, the
+// partial slabs and the result stay fp32.  Same decomposition as above (a 64x64 channel tile for all taps per workgroup,
+// split-K over (image, row chunk, pixel strip), one slab per workgroup, deterministic reduce), with what the 16x faster
+// pipe needs:
+//   * strips of 64 pixels (4 MFMA k-steps per tap and row), so that a row's MFMA work covers the LDS-DMA of the next row;
+//   * both operands are K-major in memory (pixel rows of 64 channels = 128 B) but the MFMA wants them K-minor per lane:
+//     the fragments are read with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-per-lane),
+//     two reads per operand fragment, no VALU transposition;
+//   * LDS images are filled by LDS-DMA (8 pixels per instruction); 16-byte chunk c of pixel P sits at chunk c ^ 4((P>>1)&1):
+//     the four pixel rows a half-wave reads then fall on four disjoint bank-row quarters for every tap shift;
+//   * stride-2 taps (up-conv): X pixels are staged de-interleaved by column parity ([tx][pixel]) so that a tap reads
+//     consecutive positions;
+//   * the fused bias gradient is the sum of the fragment values a wave holds anyway (fp32 adds).
+constexpr int PWB = 64;
+template <int TY, int TX, int S>
+struct WgradBGeom {
+    static constexpr int T = TY * TX;
+    static constexpr int XPX = S == 1 ? (PWB + TX - 1 + 7) / 8 * 8 : TX * PWB;    // staged X pixel positions per row
+    static constexpr int XG = XPX / 8, YG = PWB / 8;                               // LDS-DMA instructions (8 pixels) per row
+    static constexpr int RING = 4;
+    static constexpr int XSLOT = XPX * 128, YBUF = PWB * 128;
+    static constexpr int LDS = RING * XSLOT + 2 * YBUF;
+    static_assert(TY + S <= RING, "ring too small");
+    static_assert(S == 1 || (S == 2 && TX == 2), "stride-2 staging assumes 2 taps per row");
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *p0)       // pixels +0..3 at p0, +4..7 at p0 + 4*128
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p0 + 4 * 128));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ float frag_sum(const bf16x8 &v)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)v[j];
+    return s;
+}
+
+template <int TY, int TX, int S>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
+{
+    using G = WgradBGeom<TY, TX, S>;
+    constexpr int T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *xs = smem;
+    unsigned char *ys = smem + G::RING * G::XSLOT;
+    const WgradP &p = k.p;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int ntile = k.ntile_i * k.ntile_j;
+    const int grp = logical / ntile;
+    const int tile = logical - grp * ntile;
+    const int it = tile / k.ntile_j, jt = tile - it * k.ntile_j;
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool do_bias = p.db != nullptr && !p.db_on_x && it == 0 && wi == 0;      // db[j] = sum dz: from the B fragments
+    const bool do_xbias = p.db != nullptr && p.db_on_x && jt == 0 && wj == 0;      // db[i] = sum X:  from the A fragments
+    float bsum = 0.f;
+
+    // DMA role of a lane inside an 8-pixel instruction: pixel lane>>3, LDS chunk position lane&7 <- source chunk (swizzled)
+    const int d_px = lane >> 3;
+    const int d_c = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    // fragment-read role: lane = 16 g + 4 q + pp: pixel row q of the group's 4x16 block, 8-byte piece pp; the group's channels
+    // are 16 (g & 1) .. +15 of the wave's 32, its pixels 8 (g >> 1) .. +7 of the k-step
+    const int f_q = (lane >> 2) & 3, f_pp = lane & 3, f_mh = (lane >> 4) & 1, f_h = lane >> 5;
+    const int cA = wi * 4 + f_mh * 2 + (f_pp >> 1), cB = wj * 4 + f_mh * 2 + (f_pp >> 1);
+    const int yoff = (8 * f_h + f_q) * 128 + ((cB ^ (((f_q >> 1) & 1) << 2)) * 16) + (f_pp & 1) * 8;
+    int xoff[TX];
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx) {
+        if (S == 1) xoff[tx] = (8 * f_h + f_q + tx) * 128 + ((cA ^ ((((f_q + tx) >> 1) & 1) << 2)) * 16) + (f_pp & 1) * 8;
+        else xoff[tx] = (tx * PWB + 8 * f_h + f_q) * 128 + ((cA ^ (((f_q >> 1) & 1) << 2)) * 16) + (f_pp & 1) * 8;
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.X, 0, k.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)p.Y, 0, k.ybytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+
+    for (int P = grp; P < k.nparts; P += k.ngroups) {
+    const int strip = P % k.nstrips;
+    const int pc = P / k.nstrips;
+    const int chunk = pc % k.nchunks;
+    const int img = pc / k.nchunks;
+    const int x0 = p.xwin0 + strip * k.pw;
+    int pwv = p.xwin1 - x0; pwv = pwv < k.pw ? pwv : k.pw;           // valid pixels in this strip
+    const int ya = p.ywin0 + chunk * k.rows_per_chunk;
+    int yb = ya + k.rows_per_chunk; yb = yb < p.ywin1 ? yb : p.ywin1;
+    const int nks = (pwv + 15) >> 4;
+    const int xcol0 = (x0 + p.ox0) * S - p.xpad;
+
+    auto stage_x = [&](int xr, int g) {
+        const int pos = 8 * g + d_px;
+        int xc; bool ok;
+        if (S == 1) { xc = xcol0 + pos; ok = true; }
+        else { const int tx = pos / PWB, px = pos - tx * PWB; xc = xcol0 + 2 * px + tx; ok = px < pwv; }
+        ok = ok && (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW;
+        const int off = (((img * p.XH + xr) * p.XW + xc) * p.XC + p.xc0 + it * 64 + d_c * 8) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(xs + (xr & (G::RING - 1)) * G::XSLOT + g * 1024), 16,
+                                                 ok ? off : OOB, 0, 0, 0);
+    };
+    auto stage_y = [&](int y, int buf, int g) {
+        const int px = 8 * g + d_px;
+        const bool ok = px < pwv;
+        const int off = (((img * p.YH + y) * p.YW + x0 + px) * p.YC + p.yc0 + jt * 64 + d_c * 8) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (__attribute__((address_space(3))) void *)(ys + buf * G::YBUF + g * 1024), 16, ok ? off : OOB, 0, 0, 0);
+    };
+    // items of one step: S new X rows (XG groups each) then the Y row; round-robin over waves.  Groups past the strip's
+    // last needed pixel are skipped (their LDS content is never read: k-steps stop at nks).
+    const int xg_used = S == 1 ? ((16 * nks + TX - 1 + 7) >> 3) : G::XG;
+    const int yg_used = 2 * nks;
+    auto stage_step = [&](int y, int buf, int first_row, int nrows) {
+        const int xr_base = (y + p.oy0) * S - p.xpad;
+        const int nx = nrows * xg_used;
+        for (int e = wave; e < nx + yg_used; e += 4) {
+            if (e < nx) {
+                const int rr = e / xg_used;
+                stage_x(xr_base + first_row + rr, e - rr * xg_used);
+            } else {
+                stage_y(y, buf, e - nx);
+            }
+        }
+    };
+
+    if (ya < yb) {
+        stage_step(ya, 0, 0, TY);
+        __syncthreads();
+        for (int y = ya; y < yb; ++y) {
+            const int cur = (y - ya) & 1;
+            if (y + 1 < yb) stage_step(y + 1, cur ^ 1, TY - S, S);
+            const int xr0 = (y + p.oy0) * S - p.xpad;
+            const unsigned char *yrow = ys + cur * G::YBUF + yoff;
+            for (int ks = 0; ks < nks; ++ks) {
+                const bf16x8 b = tr_frag(yrow + ks * (16 * 128));
+                if (do_bias) bsum += frag_sum(b);
+#pragma unroll
+                for (int ty = 0; ty < TY; ++ty) {
+                    const unsigned char *xrow = xs + ((xr0 + ty) & (G::RING - 1)) * G::XSLOT + ks * (16 * 128);
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx) {
+                        const bf16x8 a = tr_frag(xrow + xoff[tx]);
+                        if (do_xbias) bsum += frag_sum(a);
+                        acc[ty * TX + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * TX + tx], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    }   // partitions of this workgroup
+
+    float *slab = p.slab + (size_t)grp * k.pstride;
+    if (do_bias || do_xbias) {
+        const float v = bsum + __shfl_xor(bsum, 32, 64);
+        if (lane < 32) slab[(size_t)T * p.Ci * p.Cj + (do_xbias ? it * 64 + wi * 32 : jt * 64 + wj * 32) + lane] = v;
+    }
+    f32x4 *dst4 = (f32x4 *)(slab + ((size_t)(tile * 4 + wave) * T) * 1024) + lane;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            dst4[(t * 4 + rq) * 64] = f32x4{acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]};
+}
+
 // out[i*si + j*sj + t*st] = sum_P slab_P(t,i,j)  and  db[j] = sum_P slab[P][T*Ci*Cj + j], in a fixed order.
 // Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
 // even when the output is tiny (64x64x9) and the partition count is in the thousands.
@@ -285,9 +466,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 static void decompose(const WgradP &p, WgradK &k)
 {
     const int wx = p.xwin1 - p.xwin0, wy = p.ywin1 - p.ywin0;
-    k.nstrips = cdiv(wx, PWMAX);
+    const int pwmax = p.math == 2 ? PWB : PWMAX;
+    k.nstrips = cdiv(wx, pwmax);
     int pw = cdiv(wx, k.nstrips);
-    pw = (pw + 1) & ~1;                       // even: MFMA K is a pixel pair
+    pw = p.math == 2 ? (pw + 15) & ~15 : (pw + 1) & ~1;       // whole MFMA k-steps: 16 pixels (bf16) / a pixel pair (fp32)
+    if (pw > pwmax) pw = pwmax;
     k.pw = pw;
     k.nstrips = cdiv(wx, pw);
     k.ntile_i = p.Ci / 64;
@@ -302,7 +485,7 @@ static void decompose(const WgradP &p, WgradK &k)
     // the search is a few million cheap iterations: memoise per shape (hot calls hit the cache)
     static std::mutex mu;
     static std::map<std::array<long, 4>, std::pair<int, int>> cache;
-    const std::array<long, 4> key = {per_chunk, (long)wy, (long)ntile, (long)slots};
+    const std::array<long, 4> key = {per_chunk, (long)wy, (long)ntile, (long)slots};       // (the strip width is folded into per_chunk)
     {
         std::lock_guard<std::mutex> lk(mu);
         auto itc = cache.find(key);
@@ -400,10 +583,32 @@ static int launch_wgrad_t(const WgradK &k, hipStream_t st)
     return 0;
 }
 
+template <int TY, int TX, int S>
+static int launch_wgrad_b(WgradK &k, hipStream_t st)
+{
+    using G = WgradBGeom<TY, TX, S>;
+    static bool attr_done[64] = {false};
+    auto kern = wgrad_bf16_kernel<TY, TX, S>;
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, G::LDS, attr_done)) return rc_;
+    const size_t xb = (size_t)k.p.NB * k.p.XH * k.p.XW * k.p.XC * 2, yb = (size_t)k.p.NB * k.p.YH * k.p.YW * k.p.YC * 2;
+    ARG_CHECK(xb < 0x7FFFFFFFull && yb < 0x7FFFFFFFull, "wgrad (bf16): tensor exceeds 2 GiB");
+    k.xbytes = (int)xb; k.ybytes = (int)yb;
+    char tag[96];
+    snprintf(tag, sizeof(tag), "wgradb<%d;%d;%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
+             k.p.ywin1 - k.p.ywin0, k.nparts, k.pw, k.rows_per_chunk, k.ngroups);
+    const double rows = (double)k.p.NB * (k.p.ywin1 - k.p.ywin0) * k.nstrips;
+    prof_begin(PK_WGRAD, tag, st, wgrad_alg_flops(k.p), 2.0 * rows * k.pw * G::T * k.p.Ci * k.p.Cj, wgrad_alg_bytes(k.p) / 2.0 + 2.0 * G::T * k.p.Ci * k.p.Cj);
+    hipLaunchKernelGGL(kern, dim3(k.ngroups * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_wgrad(WgradP p, hipStream_t st)
 {
     ARG_CHECK(p.Ci % 64 == 0 && p.Cj % 64 == 0 && p.Ci > 0 && p.Cj > 0, "wgrad: channel tiles must be multiples of 64 (Ci=%d Cj=%d)", p.Ci, p.Cj);
     ARG_CHECK(p.XC % 4 == 0 && p.YC % 4 == 0 && p.xc0 % 4 == 0 && p.yc0 % 4 == 0, "wgrad: channel pitch/offset must be multiples of 4");
+    if (p.math == 2) ARG_CHECK(p.XC % 8 == 0 && p.YC % 8 == 0 && p.xc0 % 8 == 0 && p.yc0 % 8 == 0, "wgrad (bf16): channel pitch/offset must be multiples of 8");
     ARG_CHECK(p.ywin0 >= 0 && p.ywin1 <= p.YH && p.xwin0 >= 0 && p.xwin1 <= p.YW && p.ywin0 < p.ywin1 && p.xwin0 < p.xwin1, "wgrad: bad window");
     ARG_CHECK((size_t)p.NB * p.XH * p.XW * p.XC < 0x7FFFFFFFull * 2 && (size_t)p.NB * p.YH * p.YW * p.YC < 0x7FFFFFFFull * 2, "wgrad: tensor too large");
     p.zeros = zero_page();
@@ -422,9 +627,9 @@ int launch_wgrad(WgradP p, hipStream_t st)
     int rc;
     const int mode = p.math == 3 ? 0 : p.math;     // mode 3 (Winograd) falls back to the exact fp32 kernel for the shapes wgradw.hip does not take
     if (p.TY == 3 && p.TX == 3 && p.stride == 1)
-        rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_t<3, 3, 1, 1>(k, st);
+        rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_b<3, 3, 1>(k, st);
     else if (p.TY == 2 && p.TX == 2 && p.stride == 2)
-        rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_t<2, 2, 2, 1>(k, st);
+        rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_b<2, 2, 2>(k, st);
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
     const int ndb = p.db ? (p.db_on_x ? p.Ci : p.Cj) : 0;

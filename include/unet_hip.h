@@ -56,8 +56,12 @@ int unet_abi_version(void);
  *     multiplies of the direct correlation, all arithmetic fp32, same parity tolerances as mode 0),
  * 0 = fp32 on the fp32 MFMA, direct correlation everywhere (fmaf-chain numerics),
  * 1 = bf16x3: fp32 operands split into two bf16 terms, three bf16 MFMAs per product, fp32 accumulation
- *     (~16-bit products; logits stay within ~1e-5 of fp32), 2 = bf16 operands, fp32 accumulation and storage
- *     (BASELINE config #3).  Tensors in HBM stay fp32 in every mode.  Also settable with UNET_MATH.           */
+ *     (~16-bit products; logits stay within ~1e-5 of fp32),
+ * 2 = bf16 (BASELINE config #3): activations, their gradients and the packed filters are bf16 IN HBM (NHWC, 2 B/element;
+ *     the workspace halves), every contraction runs on the bf16 matrix cores with fp32 accumulation; parameters, their
+ *     gradients, biases, the input image, logits and dlogits stay fp32 (fp32 master weights).  In this mode the per-op
+ *     entry points below take bf16 activation / activation-gradient tensors where they take fp32 in the other modes.
+ * Also settable with UNET_MATH.                                                                                       */
 int unet_set_math(int mode);
 int unet_get_math(void);
 /* Operand staging of the MFMA kernels: 1 (default) = LDS-DMA through buffer descriptors whenever every tensor of a launch is
@@ -107,6 +111,9 @@ int unet_backward_stage_params(int stage, int *idx, int cap);
 
 /* Algorithmic FLOPs (2*MAC) of one forward / forward+backward for B tiles of S. */
 double unet_flops(const unet_handle *h, int B, int S, int backward);
+
+/* Element size of the workspace's activation tensors for this handle's arithmetic: 2 (bf16, mode 2) or 4 (fp32). */
+int unet_activation_bytes(const unet_handle *h);
 
 /* Debug/introspection: byte offset into the workspace, extent e and channel count of a named NHWC
  * [B,e,e,C] buffer of the plan for (B,S,training): activations "a1_l","a2_l" (l=0..4), "t_l","u_l",

@@ -1,0 +1,203 @@
+"""Arithmetic mode 2 (BASELINE config #3): bf16 tensors in HBM, bf16 MFMA, fp32 accumulation.  Per-op parity of the bf16
+kernels through the C ABI.  Inputs and weights are bf16-representable, so the fp64 reference sees exactly the operands
+the kernels see: what remains is fp32 accumulation (gradients w.r.t. parameters stay fp32: tolerance 2e-5 as in fp32) and
+ONE rounding of each bf16 output (half an ulp = 2^-9 of the element, i.e. <= 2^-9 of the tensor scale: tolerance 2.5e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 2e-5
+TOL_BF16 = 2.5e-3
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import _hip
+    _hip.lib()
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    default = _hip.lib().unet_get_math()
+    _hip.check(_hip.lib().unet_set_math(2), "set_math")
+    yield _hip
+    _hip.check(_hip.lib().unet_set_math(default), "set_math")
+
+
+def nerr(a, ref):
+    a = a.detach().double().cpu(); ref = ref.detach().double().cpu()
+    return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-300)).item()
+
+
+def bf(t):          # round to bf16, keep as fp64 for the reference
+    return t.float().to(torch.bfloat16).double()
+
+
+def nhwc16(t):      # NCHW fp64 (bf16-representable) -> NHWC bf16 on the device
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).double().cpu()
+
+
+class Keep(list):
+    def __call__(self, t):
+        self.append(t)
+        return t
+
+
+def scratch(nbytes):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+@pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 45, 64, 64), (1, 66, 512, 512)])
+def test_conv3x3_fwd_bf16(hip, B, H, C, K):
+    keep = Keep()
+    x = bf(rnd(B, C, H, H, seed=1)); w = bf(rnd(K, C, 3, 3, seed=2, scale=0.05)); b = rnd(K, seed=3).float().double()
+    ref = F.relu(F.conv2d(x, w, b))
+    y = torch.empty(B, H - 2, H - 2, K, device="cuda", dtype=torch.bfloat16)
+    sc = scratch(hip.lib().unet_conv3x3_scratch_bytes(C, K))
+    hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc16(x))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.float().cuda())),
+                                         hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc), hip.stream()), "conv3x3_fwd")
+    assert nerr(nchw(y), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 24, 4, 64, 64, 64), (2, 30, -3, 64, 64, 128)])
+def test_conv3x3_fwd_virtual_concat_bf16(hip, B, Hs, pad, C1, C2, K):
+    keep = Keep()
+    H = Hs + 2 * pad
+    a = bf(rnd(B, C1, Hs, Hs, seed=1)); u = bf(rnd(B, C2, H, H, seed=2))
+    w = bf(rnd(K, C1 + C2, 3, 3, seed=3, scale=0.05)); b = rnd(K, seed=4).float().double()
+    ref = F.relu(F.conv2d(torch.cat((F.pad(a, (pad,) * 4), u), 1), w, b))
+    y = torch.empty(B, H - 2, H - 2, K, device="cuda", dtype=torch.bfloat16)
+    sc = scratch(hip.lib().unet_conv3x3_scratch_bytes(C1 + C2, K))
+    hip.check(hip.lib().unet_conv3x3_fwd(hip.ptr(keep(nhwc16(a))), Hs, Hs, C1, pad, hip.ptr(keep(nhwc16(u))), C2, B, H, H,
+                                         hip.ptr(keep(w.float().cuda())), hip.ptr(keep(b.float().cuda())), K, 1, hip.ptr(y), hip.ptr(sc),
+                                         hip.stream()), "conv3x3_fwd concat")
+    assert nerr(nchw(y), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True), (2, 13, 128, 256, True, True),
+                                                      (1, 70, 64, 64, True, False), (1, 66, 512, 512, True, True), (1, 150, 64, 64, False, False)])
+def test_conv3x3_bwd_bf16(hip, B, H, C, K, use_mask, use_add):
+    keep = Keep()
+    x = bf(rnd(B, C, H, H, seed=1)).requires_grad_(True)
+    w = bf(rnd(K, C, 3, 3, seed=2, scale=0.05)).requires_grad_(True)
+    dz = bf(rnd(B, K, H - 2, H - 2, seed=3))
+    mask = bf(rnd(B, C, H, H, seed=4).clamp_min(0)) if use_mask else None
+    add = bf(rnd(B, C, H, H, seed=5)) if use_add else None
+    F.conv2d(x, w).backward(dz)
+    dx_ref = x.grad.clone()
+    if add is not None:
+        dx_ref = dx_ref + add
+    if mask is not None:
+        dx_ref = dx_ref * (mask > 0)
+    dx = torch.empty(B, H, H, C, device="cuda", dtype=torch.bfloat16)
+    dw = torch.empty(K, C, 3, 3, device="cuda"); db = torch.empty(K, device="cuda")
+    sc = scratch(hip.lib().unet_conv3x3_bwd_scratch_bytes(B, H, H, C, K))
+    hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(keep(nhwc16(x.detach()))), H, H, C, 0, None, 0, B, H, H, hip.ptr(keep(w.detach().float().cuda())), K,
+                                         hip.ptr(keep(nhwc16(dz))), hip.ptr(dx), hip.ptr(keep(nhwc16(mask))) if use_mask else None,
+                                         hip.ptr(keep(nhwc16(add))) if use_add else None, None, None, hip.ptr(dw), hip.ptr(db),
+                                         hip.ptr(sc), hip.stream()), "conv3x3_bwd")
+    assert nerr(nchw(dx), dx_ref) < TOL_BF16
+    assert nerr(dw, w.grad) < TOL_F32                    # fp32 result of exact bf16 products: only the summation order differs
+    assert nerr(db, dz.sum((0, 2, 3))) < TOL_F32
+
+
+@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 24, 4, 64, 64), (2, 30, -3, 64, 128)])
+def test_conv3x3_bwd_virtual_concat_bf16(hip, B, Hs, pad, C, K):
+    keep = Keep()
+    H = Hs + 2 * pad
+    a = bf(rnd(B, C, Hs, Hs, seed=1)).requires_grad_(True); u = bf(rnd(B, C, H, H, seed=2)).requires_grad_(True)
+    w = bf(rnd(K, 2 * C, 3, 3, seed=3, scale=0.05)).requires_grad_(True)
+    dz = bf(rnd(B, K, H - 2, H - 2, seed=4))
+    F.conv2d(torch.cat((F.pad(a, (pad,) * 4), u), 1), w).backward(dz)
+    dx1 = torch.empty(B, Hs, Hs, C, device="cuda", dtype=torch.bfloat16); dx2 = torch.empty(B, H, H, C, device="cuda", dtype=torch.bfloat16)
+    dw = torch.empty(K, 2 * C, 3, 3, device="cuda"); db = torch.empty(K, device="cuda")
+    sc = scratch(hip.lib().unet_conv3x3_bwd_scratch_bytes(B, H, H, 2 * C, K))
+    hip.check(hip.lib().unet_conv3x3_bwd(hip.ptr(keep(nhwc16(a.detach()))), Hs, Hs, C, pad, hip.ptr(keep(nhwc16(u.detach()))), C, B, H, H,
+                                         hip.ptr(keep(w.detach().float().cuda())), K, hip.ptr(keep(nhwc16(dz))), hip.ptr(dx1), None, None,
+                                         hip.ptr(dx2), None, hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()), "conv3x3_bwd concat")
+    assert nerr(nchw(dx1), a.grad) < TOL_BF16
+    assert nerr(nchw(dx2), u.grad) < TOL_BF16
+    assert nerr(dw, w.grad) < TOL_F32
+    assert nerr(db, dz.sum((0, 2, 3))) < TOL_F32
+
+
+@pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 4, 1024, 512), (1, 40, 128, 64)])
+def test_upconv2_fwd_bwd_bf16(hip, B, H, Ci, Co):
+    keep = Keep()
+    x = bf(rnd(B, Ci, H, H, seed=1).clamp_min(0)).requires_grad_(True)
+    w = bf(rnd(Ci, Co, 2, 2, seed=2, scale=0.05)).requires_grad_(True); b = rnd(Co, seed=3).float().double()
+    dy = bf(rnd(B, Co, 2 * H, 2 * H, seed=4))
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    ref.backward(dy)
+    sc = scratch(hip.lib().unet_upconv2_scratch_bytes(B, H, H, Ci, Co))
+    y = torch.empty(B, 2 * H, 2 * H, Co, device="cuda", dtype=torch.bfloat16)
+    xd = nhwc16(x.detach())
+    hip.check(hip.lib().unet_upconv2_fwd(hip.ptr(xd), B, H, H, Ci, hip.ptr(keep(w.detach().float().cuda())), hip.ptr(keep(b.float().cuda())), Co,
+                                         hip.ptr(y), hip.ptr(sc), hip.stream()), "upconv2_fwd")
+    assert nerr(nchw(y), ref) < TOL_BF16
+    dx = torch.empty(B, H, H, Ci, device="cuda", dtype=torch.bfloat16); dw = torch.empty(Ci, Co, 2, 2, device="cuda"); db = torch.empty(Co, device="cuda")
+    hip.check(hip.lib().unet_upconv2_bwd(hip.ptr(xd), B, H, H, Ci, hip.ptr(keep(w.detach().float().cuda())), Co, hip.ptr(keep(nhwc16(dy))),
+                                         hip.ptr(dx), hip.ptr(xd), hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()), "upconv2_bwd")
+    assert nerr(nchw(dx), x.grad * (x.detach() > 0)) < TOL_BF16
+    assert nerr(dw, w.grad) < TOL_F32
+    assert nerr(db, dy.sum((0, 2, 3))) < TOL_F32
+
+
+def test_pool_head_conv1ch_bf16(hip):
+    keep = Keep()
+    # pool: a selection, exact in bf16 (ties -> first maximum)
+    B, H, Cc = 2, 12, 64
+    pre = bf(rnd(B, Cc, H, H, seed=1).clamp_min(0))
+    pre[0, :, 0:2, 0:2] = 0.0
+    pre[1, 3, 4:6, 4:6] = 1.25
+    p = pre.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(F.relu(p), 2, 2)
+    dy = bf(rnd(B, Cc, H // 2, H // 2, seed=2))
+    y_ref.backward(dy)
+    y = torch.empty(B, H // 2, H // 2, Cc, device="cuda", dtype=torch.bfloat16); dpre = torch.empty(B, H, H, Cc, device="cuda", dtype=torch.bfloat16)
+    xd = nhwc16(pre)
+    hip.check(hip.lib().unet_maxpool2_fwd(hip.ptr(xd), hip.ptr(y), B, H, H, Cc, hip.stream()))
+    hip.check(hip.lib().unet_maxpool2_bwd(hip.ptr(xd), hip.ptr(keep(nhwc16(dy))), hip.ptr(dpre), B, H, H, Cc, hip.stream()))
+    assert torch.equal(nchw(y), y_ref.detach()) and torch.equal(nchw(dpre), p.grad)
+    # head: bf16 activations in, fp32 logits out; backward writes bf16 dz and fp32 dw / db
+    B, H, Cc = 2, 37, 64
+    x = bf(rnd(B, Cc, H, H, seed=1).clamp_min(0)).requires_grad_(True)
+    w = rnd(2, Cc, 1, 1, seed=2, scale=0.1).float().double().requires_grad_(True); b = rnd(2, seed=3).float().double()
+    ref = F.conv2d(x, w, b)
+    dl = rnd(B, 2, H, H, seed=4).float().double()
+    ref.backward(dl)
+    logits = torch.empty(B, 2, H, H, device="cuda")
+    xd = nhwc16(x.detach())
+    hip.check(hip.lib().unet_head1x1_fwd(hip.ptr(xd), B, H, H, Cc, hip.ptr(keep(w.detach().float().cuda())), hip.ptr(keep(b.float().cuda())),
+                                         hip.ptr(logits), hip.stream()))
+    assert nerr(logits, ref) < TOL_F32
+    dz = torch.empty(B, H, H, Cc, device="cuda", dtype=torch.bfloat16); dw = torch.empty(2, Cc, 1, 1, device="cuda"); db = torch.empty(2, device="cuda")
+    sc = scratch(hip.lib().unet_head1x1_bwd_scratch_bytes(B, H, H, Cc))
+    hip.check(hip.lib().unet_head1x1_bwd(hip.ptr(xd), B, H, H, Cc, hip.ptr(keep(w.detach().float().cuda())), hip.ptr(keep(dl.float().cuda())),
+                                         hip.ptr(dz), hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream()))
+    assert nerr(nchw(dz), x.grad * (x.detach() > 0)) < TOL_BF16
+    assert nerr(dw, w.grad) < TOL_F32 and nerr(db, dl.sum((0, 2, 3))) < TOL_F32
+    # conv11c: fp32 image in, bf16 activations out; weight gradient from bf16 dz
+    B, S, K = 2, 60, 64
+    xi = rnd(B, 1, S, S, seed=1).float().double(); wi = rnd(K, 1, 3, 3, seed=2).float().double().requires_grad_(True); bi = rnd(K, seed=3).float().double()
+    z = F.conv2d(xi, wi, bi)
+    yo = torch.empty(B, S - 2, S - 2, K, device="cuda", dtype=torch.bfloat16)
+    hip.check(hip.lib().unet_conv1ch_fwd(hip.ptr(keep(xi.float().cuda())), B, S, hip.ptr(keep(wi.detach().float().cuda())), hip.ptr(keep(bi.float().cuda())), K,
+                                         hip.ptr(yo), hip.stream()))
+    assert nerr(nchw(yo), F.relu(z.detach())) < TOL_BF16
+    dzi = bf(rnd(B, K, S - 2, S - 2, seed=4))
+    z.backward(dzi)
+    dwi = torch.empty(K, 1, 3, 3, device="cuda"); dbi = torch.empty(K, device="cuda")
+    sc = scratch(hip.lib().unet_conv1ch_bwd_scratch_bytes(B, S, K))
+    hip.check(hip.lib().unet_conv1ch_bwd(hip.ptr(keep(xi.float().cuda())), B, S, K, hip.ptr(keep(nhwc16(dzi))), hip.ptr(dwi), hip.ptr(dbi), hip.ptr(sc), hip.stream()))
+    assert nerr(dwi, wi.grad) < TOL_F32 and nerr(dbi, dzi.sum((0, 2, 3))) < TOL_F32
