@@ -209,15 +209,17 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
     auto stage = [&](int buf) {
         unsigned char *abase = smem + buf * STAGE + wave * (8 * 128);
         unsigned char *bbase = abase + A_BYTES;
+        // the tap / channel step goes into the VECTOR offset: the range check sees only that part, and a row whose tap-0
+        // pixel lies in the virtual padding has a negative base although this tap's pixel is inside the tensor
         const int so = (toff + kc) * 2;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            int vo = a_off[i];
+            int vo = a_off[i] + so;
             if (PAD) {
                 const bool inb = (unsigned)(a_iy[i] + ty) < (unsigned)sH && (unsigned)(a_ix[i] + tx) < (unsigned)sW;
                 vo = inb ? vo : (int)0x80000000;
             }
-            bbuf_lds16(rs_a, abase + i * (32 * 128), vo, so);
+            bbuf_lds16(rs_a, abase + i * (32 * 128), vo, 0);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) bbuf_lds16(rs_b, bbase + j * (32 * 128), b_off[j], kglob * 2);

@@ -232,7 +232,9 @@ static int conv_fwd_launch(const float *x1, int H1, int C1, int pad1, const floa
     int w0 = pad1 - 2; if (w0 < 0) w0 = 0;
     int w1 = pad1 + H1; if (w1 > Ho) w1 = Ho;
     static const double split_thr = [] { const char *e = getenv("UNET_SPLIT_THR"); return e ? atof(e) : 0.85; }();
-    const bool split = x2 && pad1 > 0 && (double)(w1 - w0) * (w1 - w0) < split_thr * (double)Ho * Ho;
+    // (not with bf16 tensors: the partial sum between the two launches would be rounded to bf16 — a second rounding of
+    //  the layer's output — and the zero-padded taps cost that mode no memory traffic, only cheap MFMA time)
+    const bool split = x2 && pad1 > 0 && t_math != 2 && (double)(w1 - w0) * (w1 - w0) < split_thr * (double)Ho * Ho;
     if (!split) {
         IgemmP p = conv_fwd_desc(x1, H1, H1, C1, pad1, x2, x2 ? C2 : 0, B, H, H, wt, bias, K, relu, y);
         if ((rc = with_wino(p, wu, L, 0, 0, st))) return rc;

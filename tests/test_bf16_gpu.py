@@ -1,7 +1,7 @@
 """Arithmetic mode 2 (BASELINE config #3): bf16 tensors in HBM, bf16 MFMA, fp32 accumulation.  Per-op parity of the bf16
 kernels through the C ABI.  Inputs and weights are bf16-representable, so the fp64 reference sees exactly the operands
 the kernels see: what remains is fp32 accumulation (gradients w.r.t. parameters stay fp32: tolerance 2e-5 as in fp32) and
-ONE rounding of each bf16 output (half an ulp = 2^-9 of the element, i.e. <= 2^-9 of the tensor scale: tolerance 2.5e-3)."""
+ONE rounding of each bf16 output (half an ulp: 8 significant bits, at most 2^-8 = 3.9e-3 of the element and so of the tensor scale: tolerance 4e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 2e-5
-TOL_BF16 = 2.5e-3
+TOL_BF16 = 4e-3
 
 
 @pytest.fixture(scope="module")
