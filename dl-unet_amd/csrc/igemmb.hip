@@ -11,9 +11,12 @@
 //   * K step = 64 channels of one tap (4 MFMA k-steps), double buffered, one barrier per step;
 //   * epilogue: each wave transposes its 32 x 64 accumulator slabs through LDS and stores 16 bytes per lane (8 channels),
 //     128 contiguous bytes per pixel row, with bias / +add / ReLU (deferred-ReLU window) / ReLU' mask fused.
-// What bounds it: staging.  A 128x128 tile needs (128+128) x 128 B per 512 MFMA cycles per wave = 64 B/clk/CU at two
-// workgroups per CU against the ~29 B/clk/CU a CU takes in from L2 (MI355X_MICROARCH.md, "Indexed rows"); the 3x3
-// layers therefore use the halo-tile kernel below, which fetches an input pixel once for all 9 taps.
+// Measured (B = 8 layers of the net, rocprofv3 PMC): MFMA pipe 0.32-0.37 busy, LDS bank-conflict ratio 0.02-0.07, 550-925
+// TFLOP/s per layer.  A halo-tile variant (8 x 32 pixel output tile, the 10 x 34 input pixels staged once per 64-channel chunk
+// for all 9 taps, 3x less L2 -> LDS traffic, one 512-thread workgroup per CU) was built, was correct, and was measured
+// interleaved in one process against this kernel on every 3x3 layer: 0.93x-1.35x the time (faster only on conv42c) — its
+// single workgroup per CU exposes the halo prologue and the epilogue, and its 8 lockstep waves all read their fragments right
+// after each barrier.  It was removed; DESIGN.md section 4c has the numbers.
 #include "common.hpp"
 #include "igemm_epilogue.hpp"
 #include <cstdio>
@@ -39,17 +42,16 @@ __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_
 constexpr int EPB_PITCH = 68;
 constexpr int EPB_WAVE_BYTES = 32 * EPB_PITCH * 4;          // 8704
 
-template <int BM, int BN>
-__device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
+// row tables of a linear-M tile: element offset of each tile row's pixel in dst | flags (bit 0: inside the deferred-ReLU
+// window, bit 1: row outside the output domain)
+template <int BM>
+__device__ __forceinline__ void igemmb_rows_linear(const IgemmP &p, int m0, int tid, unsigned *rowoff, unsigned char *rflag)
 {
-    constexpr int WN = BN / 64;
-    unsigned *rowoff = (unsigned *)lds;                                   // [BM] element offset of each tile row's pixel in dst
-    unsigned char *inwin = lds + BM * 4;                                  // [BM] deferred-ReLU flags
-    float *patch0 = (float *)(lds + BM * 4 + ((BM + 15) & ~15));
     if (tid < BM) {
         const bool relu_win = p.rw1 > p.rw0;
         int m = m0 + tid;
-        m = m < p.M ? m : p.M - 1;
+        const bool valid = m < p.M;
+        m = valid ? m : p.M - 1;
         unsigned off;
         unsigned char flag = 0;
         if (!p.scatter && !relu_win) {
@@ -66,28 +68,34 @@ __device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2
             flag = relu_win && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
         }
         rowoff[tid] = off;
-        inwin[tid] = flag;
+        rflag[tid] = flag | (valid ? 0 : 2);
     }
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+}
+
+// TN = 32-column tiles per wave; the wave's tile rows start at `wrow0` of the workgroup tile, its columns at n0w.
+// The row tables must be complete (barrier) before the call; `patch` is the wave's private LDS area (EPB_WAVE_BYTES).
+template <int TN>
+__device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][TN], int wrow0, int n0w, int lane, float *patch,
+                                             const unsigned *rowoff, const unsigned char *rflag)
+{
+    constexpr int NL = 4 * TN;                 // lanes per row on the read-back side (8 channels each)
+    constexpr int RPP = 64 / NL;               // rows per pass
     const int l31 = lane & 31, lh = lane >> 5;
-    float *patch = patch0 + wave * (EPB_WAVE_BYTES / 4);
     const bool relu_win = p.rw1 > p.rw0;
-    const int rrow = lane >> 3, cg = lane & 7;
+    const int rrow = lane / NL, cg = lane % NL;
     const u16 *addp = (const u16 *)p.add, *maskp = (const u16 *)p.mask;
     u16 *dstp = (u16 *)p.dst;
-    const int nb = n0 + wn * 64;
-    float bv[2] = {0.f, 0.f};
-    if (p.bias) {
+    float bv[TN];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            int n = nb + tn * 32 + l31;
+    for (int tn = 0; tn < TN; ++tn) {
+        bv[tn] = 0.f;
+        if (p.bias) {
+            int n = n0w + tn * 32 + l31;
             n = n < p.Nn ? n : p.Nn - 1;
             bv[tn] = p.bias[p.cout ? n % p.cout : n];
         }
     }
-    const int n8 = nb + 8 * cg;
+    const int n8 = n0w + 8 * cg;
     const bool n_ok = n8 < p.Nn;
     const int nc = n_ok ? n8 : 0;
     int coloff;
@@ -100,17 +108,19 @@ __device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPB_PITCH + tn * 32 + l31] = acc[tm][tn][r] + bv[tn];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int trow = wm * 64 + tm * 32 + rrow + 8 * k;
-            const f32x4 lo = *(const f32x4 *)(patch + (rrow + 8 * k) * EPB_PITCH + 8 * cg);
-            const f32x4 hi = *(const f32x4 *)(patch + (rrow + 8 * k) * EPB_PITCH + 8 * cg + 4);
+        for (int k = 0; k < 32 / RPP; ++k) {
+            const int prow = rrow + RPP * k;
+            const int trow = wrow0 + tm * 32 + prow;
+            const f32x4 lo = *(const f32x4 *)(patch + prow * EPB_PITCH + 8 * cg);
+            const f32x4 hi = *(const f32x4 *)(patch + prow * EPB_PITCH + 8 * cg + 4);
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const size_t o = (size_t)rowoff[trow] + (size_t)coloff;
+            const unsigned char fl = rflag[trow];
             if (addp) {
                 const uint4 t = *(const uint4 *)(addp + o);
                 const unsigned tw[4] = {t.x, t.y, t.z, t.w};
@@ -118,7 +128,7 @@ __device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2
                 for (int c = 0; c < 4; ++c) { v[2 * c] += bf2f((u16)(tw[c] & 0xffff)); v[2 * c + 1] += bf2f((u16)(tw[c] >> 16)); }
             }
             if (p.relu) {
-                const bool defer = relu_win && inwin[trow];
+                const bool defer = relu_win && (fl & 1);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = (v[c] > 0.f || defer) ? v[c] : 0.f;
             }
@@ -132,7 +142,7 @@ __device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2
                     v[2 * c + 1] = (short)(tw[c] >> 16) > 0 ? v[2 * c + 1] : 0.f;
                 }
             }
-            if (n_ok && m0 + trow < p.M) {
+            if (n_ok && !(fl & 2)) {
                 uint4 w;
                 w.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
                 w.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
@@ -142,6 +152,20 @@ __device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2
             }
         }
     }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
+{
+    constexpr int WN = BN / 64;
+    unsigned *rowoff = (unsigned *)lds;
+    unsigned char *rflag = lds + BM * 4;
+    float *patch0 = (float *)(lds + BM * 4 + ((BM + 15) & ~15));
+    igemmb_rows_linear<BM>(p, m0, tid, rowoff, rflag);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    igemmb_store<2>(p, acc, wm * 64, n0 + wn * 64, lane, patch0 + wave * (EPB_WAVE_BYTES / 4), rowoff, rflag);
 }
 
 // ---- plain kernel: every tap re-stages its A rows (up-conv GEMMs, and any 3x3 shape the halo kernel does not take) -------

