@@ -131,6 +131,11 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
+    # stdout carries exactly one JSON line: RCCL prints its warnings to stdout, so everything else written to fd 1 during the
+    # run is sent to stderr and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -317,10 +322,11 @@ def main():
         _hip.check(L.unet_set_math(args.math), "unet_set_math")
         if rank == 0:
             out["other_math_modes"] = other
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -60,6 +60,8 @@ _SIGS = {
     "unet_class_balance": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "unet_gaussian_filter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp]),
     "unet_warp_bilinear": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "unet_rotate_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "unet_reflect_rotate_crop": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, vp, vp, vp]),
     "unet_conv3x3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "unet_conv3x3_fwd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    vp, vp, C.c_int, C.c_int, vp, vp, vp]),

@@ -4,6 +4,7 @@
 //   N3 class-balance maps     : per-image class counts -> weight map            (functions.py:82-117)
 //   N1 elastic deformation    : separable Gaussian of a uniform field, bilinear warp (data.py:225-245)
 #include "common.hpp"
+#include <cmath>
 #include "../../include/unet_hip.h"
 
 namespace unet {
@@ -146,6 +147,109 @@ __global__ __launch_bounds__(256) void warp_bilinear_kernel(const float *__restr
     }
 }
 
+
+// ---- reflect-pad + rotate + centre crop (data.py:108-125) ----------------------------------------------------------------
+//   image_pad = np.pad(image, input_size, mode='reflect'); image_rot = scipy.ndimage.rotate(image_pad, deg)   (order-3 spline,
+//   reshape=True, mode='constant'); image = image_rot[t:b, l:r]   — the S x S centre.
+// The crop only ever samples a disc of radius S/sqrt(2) around the centre of the padded image, hundreds of pixels away from
+// its border, so neither the 'constant' extension of the interpolation nor the boundary initialisation of the spline
+// prefilter can reach it (the prefilter's impulse response decays as 0.268^k).  Hence: (1) form the square of the padded image
+// around that disc (+2 for the spline support, +28 for the prefilter) by reflect indexing, (2) turn it into cubic B-spline
+// coefficients with the prefilter written as the symmetric FIR it is far from boundaries, taps sqrt(3) z^|k|, z = sqrt(3) - 2,
+// |k| <= 28 (z^28 = 1e-16), separably, (3) evaluate the spline at the rotated coordinates of the crop's pixels with scipy's
+// affine_transform geometry, (4) round like scipy does for integer images: (type)min(t > 0 ? t + 0.5 : 0, max).
+constexpr int SPL_R = 28;
+struct SplTaps { float w[2 * SPL_R + 1]; };
+struct RotGeom { double c[64], s[64], offy[64], offx[64]; int t[64], l[64]; };     // per sample: rotation, affine offset, crop origin
+
+__device__ __forceinline__ int reflect_index(int i, int n)          // numpy 'reflect': ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ...
+{
+    const int period = 2 * (n - 1);
+    if (period == 0) return 0;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+__global__ __launch_bounds__(256) void reflect_region_kernel(const float *__restrict__ img, float *__restrict__ reg, int n, int pad, int W, int y0, int x0, size_t total)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(e % W);
+        const size_t t = e / W;
+        const int yy = (int)(t % W);
+        const size_t b = t / W;
+        reg[e] = img[(b * n + reflect_index(y0 + yy - pad, n)) * n + reflect_index(x0 + xx - pad, n)];
+    }
+}
+
+__global__ __launch_bounds__(256) void spline_fir_kernel(const float *__restrict__ in, float *__restrict__ out, int W, int axis, const SplTaps taps, size_t total)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % W);
+        const size_t t = e / W;
+        const int y = (int)(t % W);
+        const size_t base = (t / W) * (size_t)W * W;
+        float acc = 0.f;
+        const int p = axis ? x : y;
+        const size_t stride = axis ? 1 : (size_t)W;
+        const size_t line = axis ? base + (size_t)y * W : base + x;
+        for (int k = -SPL_R; k <= SPL_R; ++k) {
+            const int q = p + k;
+            if ((unsigned)q < (unsigned)W) acc = fmaf(taps.w[k + SPL_R], in[line + (size_t)q * stride], acc);
+        }
+        out[e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void rotate_sample_kernel(const float *__restrict__ coef, float *__restrict__ out, int S, int W, int y0, int x0,
+                                                            const RotGeom g, float levels, size_t total)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % S);
+        const size_t t = e / S;
+        const int i = (int)(t % S);
+        const int b = (int)(t / S);
+        // scipy: input coordinate = matrix @ output coordinate + offset, matrix = [[c, s], [-s, c]] — in fp64 like scipy: at
+        // coordinates ~1000 an fp32 ulp (1e-4 px) times the slope of a noisy 8-bit image is 1e-2 grey levels, enough to move
+        // 0.4 % of the pixels across a rounding boundary
+        const double oy = (double)(g.t[b] + i), ox = (double)(g.l[b] + j);
+        const double yd = g.c[b] * oy + g.s[b] * ox + g.offy[b] - (double)y0;
+        const double xd = -g.s[b] * oy + g.c[b] * ox + g.offx[b] - (double)x0;
+        const double fyd = floor(yd), fxd = floor(xd);
+        const float fy = (float)fyd, fx = (float)fxd;
+        const float ty = (float)(yd - fyd), tx = (float)(xd - fxd);
+        float wy[4], wx[4];
+        {   // cubic B-spline weights at offsets -1, 0, 1, 2 (scipy ni_interpolation.c, order 3)
+            float z = 1.f - ty;
+            wy[1] = (ty * ty * (ty - 2.f) * 3.f + 4.f) / 6.f; wy[2] = (z * z * (z - 2.f) * 3.f + 4.f) / 6.f; wy[0] = z * z * z / 6.f; wy[3] = 1.f - wy[0] - wy[1] - wy[2];
+            z = 1.f - tx;
+            wx[1] = (tx * tx * (tx - 2.f) * 3.f + 4.f) / 6.f; wx[2] = (z * z * (z - 2.f) * 3.f + 4.f) / 6.f; wx[0] = z * z * z / 6.f; wx[3] = 1.f - wx[0] - wx[1] - wx[2];
+        }
+        const int iy = (int)fy - 1, ix = (int)fx - 1;
+        const float *cb = coef + (size_t)b * W * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = iy + a; yy = yy < 0 ? 0 : (yy > W - 1 ? W - 1 : yy);
+            float r = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int xx = ix + q; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                r = fmaf(wx[q], cb[(size_t)yy * W + xx], r);
+            }
+            acc = fmaf(wy[a], r, acc);
+        }
+        if (levels > 0.f) {
+            // scipy's conversion to an unsigned integer image (ni_interpolation.c CASE_INTERP_OUT_UINT, scipy 1.15): t > 0 ? t + 0.5 : 0,
+            // clamped to the type's maximum (cubic overshoot next to 255 stays 255), then truncated
+            float v = acc > 0.f ? acc + 0.5f : 0.f;
+            v = v > levels ? levels : v;
+            acc = floorf(v);
+        }
+        out[e] = acc;
+    }
+}
+
 static inline int grid1(size_t total, int cap = 16384)
 {
     size_t g = (total + 255) / 256;
@@ -221,6 +325,57 @@ int unet_warp_bilinear(const void *img, const void *dy, const void *dx, int B, i
     const size_t total = (size_t)B * H * W;
     hipLaunchKernelGGL(warp_bilinear_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, (const float *)img, (const float *)dy, (const float *)dx,
                        (float *)out, H, W, total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int rot_region_w(int S) { return 2 * ((int)ceil(S * 0.70711) + 2 + 2 + SPL_R) + 2; }
+size_t unet_rotate_scratch_bytes(int B, int S) { return (size_t)2 * B * rot_region_w(S) * rot_region_w(S) * sizeof(float); }
+
+int unet_reflect_rotate_crop(const void *img, int B, int n, int pad, int S, const float *angles_deg_host, int levels, void *out, void *scratch, void *stream)
+{
+    ARG_CHECK(img && out && scratch && angles_deg_host, "unet_reflect_rotate_crop: null argument");
+    ARG_CHECK(B > 0 && B <= 64 && n >= 2 && pad >= 0 && S > 0 && S % 2 == 0, "unet_reflect_rotate_crop: bad shape (1 <= B <= 64, S even)");
+    ARG_CHECK(levels == 0 || levels == 255 || levels == 65535, "unet_reflect_rotate_crop: levels must be 0 (float), 255 or 65535");
+    const int N = n + 2 * pad;                                   // padded extent
+    const int W = rot_region_w(S), Wh = (W - 2) / 2;
+    ARG_CHECK(N >= W, "unet_reflect_rotate_crop: the padded image (%d) is smaller than the region the crop samples (%d)", N, W);
+    const int c0 = (N - 1) / 2 - Wh;                             // region origin in padded coordinates (both axes)
+    RotGeom g;
+    for (int b = 0; b < B; ++b) {
+        // scipy.ndimage.rotate: exact sines/cosines of degrees, output shape from the rotated corners, centres mapped onto each other
+        const double a = angles_deg_host[b];
+        double r = fmod(a, 360.0); if (r < 0) r += 360.0;
+        double c, sn;
+        if (fmod(r, 30.0) == 0.0) {                              // scipy.special.cosdg / sindg are exact at the reference's 30-degree steps
+            static const double C30[12] = {1.0, 0.8660254037844387, 0.5, 0.0, -0.5, -0.8660254037844387, -1.0, -0.8660254037844387, -0.5, 0.0, 0.5, 0.8660254037844387};
+            const int q = (int)(r / 30.0);
+            c = C30[q]; sn = C30[(q + 9) % 12];                  // sin(x) = cos(x - 90)
+        } else { c = cos(r * M_PI / 180.0); sn = sin(r * M_PI / 180.0); }
+        const int Nout = (int)(N * (fabs(c) + fabs(sn)) + 0.5);
+        const double oc = (Nout - 1) / 2.0, ic = (N - 1) / 2.0;
+        g.c[b] = c; g.s[b] = sn;
+        g.offy[b] = ic - (c * oc + sn * oc);
+        g.offx[b] = ic - (-sn * oc + c * oc);
+        g.t[b] = Nout / 2 - S / 2; g.l[b] = Nout / 2 - S / 2;
+        ARG_CHECK(g.t[b] >= 0, "unet_reflect_rotate_crop: the rotated image is smaller than the crop");
+    }
+    SplTaps taps;
+    {
+        const double z = sqrt(3.0) - 2.0;
+        for (int k = -SPL_R; k <= SPL_R; ++k) taps.w[k + SPL_R] = (float)(sqrt(3.0) * pow(z, abs(k)));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float *reg = (float *)scratch, *tmp = reg + (size_t)B * W * W;
+    const size_t rt = (size_t)B * W * W;
+    ProfScope ps("N1.rotate");
+    prof_begin(PK_ELEMWISE, "reflect_rotate_crop", st, 0.0, 0.0, 4.0 * (5.0 * rt + (double)B * S * S));
+    hipLaunchKernelGGL(reflect_region_kernel, dim3(grid1(rt)), dim3(256), 0, st, (const float *)img, reg, n, pad, W, c0, c0, rt);
+    hipLaunchKernelGGL(spline_fir_kernel, dim3(grid1(rt)), dim3(256), 0, st, (const float *)reg, tmp, W, 1, taps, rt);
+    hipLaunchKernelGGL(spline_fir_kernel, dim3(grid1(rt)), dim3(256), 0, st, (const float *)tmp, reg, W, 0, taps, rt);
+    const size_t ot = (size_t)B * S * S;
+    hipLaunchKernelGGL(rotate_sample_kernel, dim3(grid1(ot)), dim3(256), 0, st, (const float *)reg, (float *)out, S, W, c0, c0, g, (float)levels, ot);
+    prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
 }

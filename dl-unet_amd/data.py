@@ -5,9 +5,13 @@
   mirror_transform_tensor(image)     data.py:281-312
   test_input(images)                 data.py:184-188   mirror + (x-min)/ptp for a batch (ImageDataset_test)
   elastic_transform(images, a, s)    data.py:225-245   Simard-2003 elastic deformation (N1)
+  reflect_rotate_crop(images, deg)   data.py:106-125   reflect pad + cubic-spline rotation + centre crop, fused (N1)
+  augment(image, target, ...)        data.py:97-135    ImageDataset.__getitem__ after the file reads, on the device
 
 Datasets, file readers, downloaders and the OpenCV label preprocessing are out of scope.
 """
+import ctypes as _C
+
 import numpy as np
 import torch
 
@@ -89,3 +93,52 @@ def elastic_transform(images, alpha, sigma, random_state=None, fields=None):
         _hip.run("unet_warp_bilinear", dev, _hip.ptr(x), _hip.ptr(dx), _hip.ptr(dy), B, H, W, _hip.ptr(o))
         outs.append(o.reshape(im.shape))
     return outs
+
+
+def reflect_rotate_crop(images, angles_deg, input_size=None, levels=255):
+    """images: device tensor [n,n] or [B,n,n] (the random crop of the sample, e.g. 388^2); angles_deg: one angle or B angles
+    (the reference draws one of 0,30,...,330 per sample, data.py:113).  Returns [S,S] / [B,S,S] with S = input_size: the centre
+    of scipy.ndimage.rotate(np.pad(image, S, 'reflect'), deg) (data.py:106-125), fused so the 1532^2 padded / rotated
+    images never exist.  levels=255 / 65535 reproduces scipy's rounding and clamping for the uint8 / uint16 images the reference loads;
+    levels=0 keeps the float spline value."""
+    single = images.dim() == 2
+    x = _as_batch(images).contiguous().float()
+    B, n, _ = x.shape
+    if input_size is None:
+        _, input_size, _ = input_size_compute(x)
+    S = int(input_size)
+    ang = np.atleast_1d(np.asarray(angles_deg, dtype=np.float32))
+    if ang.size == 1 and B > 1:
+        ang = np.repeat(ang, B)
+    if ang.size != B:
+        raise ValueError("need one angle per image")
+    outs = []
+    for lo in range(0, B, 64):                                    # the kernel takes up to 64 samples per call
+        xb = x[lo:lo + 64]
+        b = xb.shape[0]
+        out = torch.empty(b, S, S, dtype=torch.float32, device=x.device)
+        sc = torch.empty(_hip.lib().unet_rotate_scratch_bytes(b, S), dtype=torch.uint8, device=x.device)
+        arr = (_C.c_float * b)(*[float(a) for a in ang[lo:lo + b]])
+        _hip.run("unet_reflect_rotate_crop", x.device, _hip.ptr(xb), b, n, S, S, arr, int(levels), _hip.ptr(out), _hip.ptr(sc))
+        outs.append(out)
+    out = torch.cat(outs) if len(outs) > 1 else outs[0]
+    return out[0] if single else out
+
+
+def augment(image, target, crop_xy, crop, rot_deg, alpha, sigma, random_state=None, fields=None, levels=255):
+    """What ImageDataset.__getitem__ does to one sample after reading it (data.py:97-135), on the device.  The random draws
+    stay with the caller (crop origin from the weighted distribution + jitter, rot_deg from np.arange(0,360,30), the elastic
+    fields), so the host RNG sequence can follow the reference's:  crop -> reflect pad + rotate + centre crop -> the same
+    elastic deformation for image and mask -> mask cropped to the label extent and thresholded at 127 -> image to [0,1].
+    image / target: device tensors [H,W] (grey levels / {0,255}); returns (inp [1,S,S] float32, gt [1,crop,crop] int64)."""
+    x0, y0 = crop_xy
+    img = image[x0:x0 + crop, y0:y0 + crop]
+    tgt = target[x0:x0 + crop, y0:y0 + crop]
+    _, S, _ = input_size_compute(img)
+    both = reflect_rotate_crop(torch.stack((img.float(), tgt.float())), [rot_deg, rot_deg], S, levels=levels)
+    inp, gt = elastic_transform((both[0], both[1]), alpha, sigma, random_state=random_state, fields=fields)
+    pad = int((S - crop) / 2)
+    gt = (gt[pad:crop + pad, pad:crop + pad] > 127).long()
+    lo, hi = inp.min(), inp.max()
+    inp = (inp - lo) / (hi - lo)
+    return inp[None], gt[None]

@@ -201,6 +201,15 @@ int unet_class_balance(const void *labels_i64, int B, int H, int W, void *weight
 int unet_gaussian_filter(const void *field, int B, int H, int W, const void *weights, int radius, float scale,
                          void *tmp, void *out, void *stream);
 int unet_warp_bilinear(const void *img, const void *dy, const void *dx, int B, int H, int W, void *out, void *stream);
+/* N1, replaces the reflect pad + random rotation + centre crop of ImageDataset.__getitem__ (data.py:108-125):
+ *   np.pad(image, pad, 'reflect') -> scipy.ndimage.rotate(deg) (cubic spline, reshape=True, 'constant') -> [t:b, l:r] (S x S),
+ * fused so that only the pixels the crop samples are formed.  img fp32 [B,n,n] (n = the random crop, e.g. 388), pad = the
+ * np.pad width (the reference passes input_size = S), angles: HOST array of B degrees, out fp32 [B,S,S].
+ * levels: 0 keeps the float result; 255 / 65535 reproduce scipy's conversion for the uint8 / uint16 images the reference
+ * loads: (type)min(t > 0 ? t + 0.5 : 0, levels) (scipy 1.15).  scratch >= unet_rotate_scratch_bytes(B, S).             */
+size_t unet_rotate_scratch_bytes(int B, int S);
+int unet_reflect_rotate_crop(const void *img, int B, int n, int pad, int S, const float *angles_deg_host, int levels,
+                             void *out, void *scratch, void *stream);
 
 /* ---- per-op entry points (NHWC fp32), used by the unit tests ---------------------------------
  * Each replaces the ATen op dispatched at the cited line.  w_* are in reference layout.    */

@@ -2,7 +2,7 @@
 path.  Pinned by tests/golden/aux_golden.npz (tests/golden/make_golden_aux.py runs
 the reference's own functions here)."""
 import numpy as np
-from scipy.ndimage import gaussian_filter, map_coordinates
+from scipy.ndimage import gaussian_filter, map_coordinates, rotate
 
 
 def input_size_compute(n):
@@ -69,3 +69,17 @@ def eval_counts(pred, label):
     union = np.logical_or(pred, label).sum()
     diff = np.abs(pred.astype(np.int64) - label.astype(np.int64)).sum()
     return int(inter), int(union), int(diff)
+
+
+def reflect_rotate_crop(image, rot_deg, input_size=None):
+    """data.py:106-125 for one image (any dtype the reference loads: uint8 / uint16 / float): reflect-pad by input_size on
+    every side, scipy.ndimage.rotate (cubic spline, reshape=True, mode='constant', same dtype out), centre crop of
+    input_size x input_size."""
+    if input_size is None:
+        _, input_size, _ = input_size_compute(image.shape[-1])
+    pad = np.pad(image, pad_width=input_size, mode="reflect")
+    rot = rotate(pad, rot_deg)
+    h, w = rot.shape
+    l = w // 2 - input_size // 2; r = w // 2 + input_size // 2
+    t = h // 2 - input_size // 2; b = h // 2 + input_size // 2
+    return rot[t:b, l:r]

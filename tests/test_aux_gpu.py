@@ -142,3 +142,71 @@ def test_config5_at_its_real_batch_crosses_2GiB(dev):
             safe = margin[pad:pad + n, pad:pad + n] > 1e-5 * scale
             assert bool((mi[0][safe] == mask[i][safe]).all())
             assert (si[0] - stats[i]).abs().max().item() <= int((~safe).sum())
+
+
+def test_reflect_rotate_crop_vs_scipy_oracle(dev, golden_dir):
+    """N1: np.pad(reflect) + scipy.ndimage.rotate (cubic spline) + centre crop (data.py:106-125), fused on the device.
+    Oracle: oracle/aux_ref.reflect_rotate_crop (pinned bit-exactly to the reference's own statements by the CPU suite).
+    Float result: <= 2e-5 of the value range (fp32 prefilter and weights against scipy's fp64).  uint8 result: scipy rounds
+    t + 0.5, so a pixel whose spline value lies within fp32 noise of k + 0.5 may land on the neighbouring level: at most 1 level
+    off, on fewer than 0.1 % of the pixels; rotations by multiples of 90 degrees are pure permutations and must be exact."""
+    import data
+    from oracle import aux_ref, prng
+    g = np.load(os.path.join(golden_dir, "rotate_golden.npz"))
+    for tag in ("a", "b", "c", "d"):
+        crop, seed, deg, S = [int(v) for v in g["%s_params" % tag]]
+        st = int(g["%s_stride" % tag])
+        img = (prng.uniform01(9, seed, crop * crop).reshape(crop, crop) * 255).astype(np.uint8)
+        tgt = ((prng.uniform01(9, 100 + seed, crop * crop).reshape(crop, crop) > 0.5) * 255).astype(np.uint8)
+        both = torch.from_numpy(np.stack([img, tgt]).astype(np.float32)).to(dev)
+        out = data.reflect_rotate_crop(both, [deg, deg], S, levels=255).cpu().numpy()
+        for k, src in enumerate((img, tgt)):
+            ref = aux_ref.reflect_rotate_crop(src, deg).astype(np.int64)
+            d = np.abs(out[k].astype(np.int64) - ref)
+            assert d.max() <= 1 and (d > 0).mean() < 1e-3, (tag, k, d.max(), (d > 0).mean())
+            assert np.abs(out[k][::st, ::st].astype(np.int64) - g["%s_%s_sample" % (tag, ("img", "tgt")[k])].astype(np.int64)).max() <= 1
+        fl = data.reflect_rotate_crop(both[0], deg, S, levels=0).cpu().numpy()
+        ref = aux_ref.reflect_rotate_crop(img.astype(np.float64), deg)
+        assert np.abs(fl - ref).max() < 255 * 2e-5
+    # all twelve angles of the reference (np.arange(0, 360, 30)) on one image; 0/90/180/270 are exact
+    crop = 36
+    img = (prng.uniform01(9, 50, crop * crop).reshape(crop, crop) * 255).astype(np.uint8)
+    x = torch.from_numpy(np.repeat(img[None].astype(np.float32), 12, axis=0)).to(dev)
+    out = data.reflect_rotate_crop(x, list(range(0, 360, 30)), levels=255).cpu().numpy()
+    for i, deg in enumerate(range(0, 360, 30)):
+        ref = aux_ref.reflect_rotate_crop(img, deg).astype(np.int64)
+        d = np.abs(out[i].astype(np.int64) - ref)
+        assert d.max() <= (0 if deg % 90 == 0 else 1) and (d > 0).mean() < 1e-3, (deg, d.max(), (d > 0).mean())
+    # the reference's real size: 388 crop -> 572 input, angle as drawn by the reference
+    crop, seed, deg, S = [int(v) for v in g["full_params"]]
+    img = (prng.uniform01(9, seed, crop * crop).reshape(crop, crop) * 255).astype(np.uint8)
+    out = data.reflect_rotate_crop(torch.from_numpy(img.astype(np.float32)).to(dev), deg, levels=255).cpu().numpy()
+    assert out.shape == (S, S) and np.array_equal(out[::4, ::4].astype(np.uint8), g["full_img_sample"])
+    assert int(out.astype(np.int64).sum()) == int(g["full_sums"][0])
+
+
+def test_augment_pipeline_on_device(dev):
+    """ImageDataset.__getitem__ after the file reads (data.py:97-135): crop -> reflect pad + rotation + centre crop -> elastic
+    deformation shared by image and mask -> label crop + threshold -> normalisation, against the same steps done with the
+    numpy/scipy oracle."""
+    import data
+    from oracle import aux_ref, prng
+    H, crop = 120, 36
+    img = (prng.uniform01(12, 1, H * H).reshape(H, H) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:H]
+    tgt = ((((yy - 60) ** 2 + (xx - 50) ** 2) < 30 ** 2) * 255).astype(np.uint8)
+    x0, y0, deg, alpha, sigma = 40, 30, 210, 200.0, 10.0
+    S = aux_ref.input_size_compute(crop)[1]
+    rs = np.random.RandomState(77)
+    f0, f1 = rs.rand(S, S), rs.rand(S, S)
+    inp, gt = data.augment(torch.from_numpy(img.astype(np.float32)).to(dev), torch.from_numpy(tgt.astype(np.float32)).to(dev),
+                           (x0, y0), crop, deg, alpha, sigma, fields=(f0, f1))
+    ri = aux_ref.reflect_rotate_crop(img[x0:x0 + crop, y0:y0 + crop], deg)
+    rt = aux_ref.reflect_rotate_crop(tgt[x0:x0 + crop, y0:y0 + crop], deg)
+    (ei, et), _, _ = aux_ref.elastic_transform((ri.astype(np.float64), rt.astype(np.float64)), alpha, sigma, (f0, f1))
+    pad = (S - crop) // 2
+    gt_ref = (et[pad:pad + crop, pad:pad + crop] > 127).astype(np.int64)
+    inp_ref = aux_ref.normalise01(ei)
+    assert inp.shape == (1, S, S) and gt.shape == (1, crop, crop) and gt.dtype == torch.int64
+    assert np.abs(inp.cpu().numpy()[0] - inp_ref).max() < 1.5 / 255              # one grey level (a rounding flip) at most
+    assert (gt.cpu().numpy()[0] != gt_ref).mean() < 5e-3

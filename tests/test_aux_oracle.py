@@ -44,3 +44,20 @@ def test_metrics_and_class_balance(golden_dir):
         assert np.array_equal(aux_ref.class_balance(lab[b]), ka["class_balance_rand"][b])
     w, r = aux_ref.gaussian_taps(10.0)
     assert r == 40 and abs(w.sum() - 1) < 1e-15
+
+
+def test_reflect_rotate_crop_oracle_vs_reference_golden(golden_dir):
+    """oracle/aux_ref.reflect_rotate_crop against the outputs of the reference's own statements (data.py:103-125, executed by
+    tests/golden/make_golden_rotate.py): integer images, bit-exact."""
+    import os
+    from oracle import aux_ref, prng
+    g = np.load(os.path.join(golden_dir, "rotate_golden.npz"))
+    for tag in ("a", "b", "c", "d", "full"):
+        crop, seed, deg, S = [int(v) for v in g["%s_params" % tag]]
+        st = int(g["%s_stride" % tag])
+        img = (prng.uniform01(9, seed, crop * crop).reshape(crop, crop) * 255).astype(np.uint8)
+        tgt = ((prng.uniform01(9, 100 + seed, crop * crop).reshape(crop, crop) > 0.5) * 255).astype(np.uint8)
+        ri = aux_ref.reflect_rotate_crop(img, deg); rt = aux_ref.reflect_rotate_crop(tgt, deg)
+        assert ri.shape == (S, S) and ri.dtype == np.uint8
+        assert np.array_equal(ri[::st, ::st], g["%s_img_sample" % tag]) and np.array_equal(rt[::st, ::st], g["%s_tgt_sample" % tag])
+        assert [int(ri.astype(np.int64).sum()), int(rt.astype(np.int64).sum())] == [int(v) for v in g["%s_sums" % tag]]
