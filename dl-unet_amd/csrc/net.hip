@@ -354,7 +354,7 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
         // split-K slab: the largest need over all weight-gradient launches
         size_t need = 0;
         auto upd = [&](const WgradP &w) { size_t n = wgrad_slab_need(w); if (n > need) need = n; };
-        if (base % 64 == 0) {
+        {
             for (int l = 0; l < 5; ++l) {
                 if (l > 0) upd(conv_wgrad_desc(nullptr, pl.ein[l], pl.ch[l - 1], 0, nullptr, pl.ea1[l], pl.ch[l], B, nullptr, pl.ch[l - 1], 0, nullptr, 0));
                 upd(conv_wgrad_desc(nullptr, pl.ea1[l], pl.ch[l], 0, nullptr, pl.ea2[l], pl.ch[l], B, nullptr, pl.ch[l], 0, nullptr, 0));
@@ -693,7 +693,6 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
         return UNET_E_NOTREADY;
     }
     ARG_CHECK(workspace_bytes >= pl.total, "unet_backward: workspace too small");
-    if (pl.base % 64 != 0) { set_error("unet_backward: base_ch %d unsupported for training (needs a multiple of 64)", pl.base); return UNET_E_UNSUPPORTED; }
     ARG_CHECK(stage >= 0 && stage < N_STAGES, "unet_backward: bad stage %d", stage);
     MathScope ms(pl.math);                   // the arithmetic the forward was planned with
     hipStream_t st = (hipStream_t)stream;

@@ -38,6 +38,7 @@ struct WgradK {               // kernel-side copy with the derived decomposition
     WgradP p;
     int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
     int xbytes, ybytes;                // bf16 kernel: buffer-descriptor sizes of X and Y
+    int ci_real, cj_real;              // channel counts of the tensors; p.Ci / p.Cj are these rounded up to whole 64-channel tiles
     int nparts, ngroups;               // pixel partitions, and workgroups per channel tile that share them
     size_t pstride;                    // floats per partition in the slab: T*Ci*Cj weights + Cj bias partials
 };
@@ -116,13 +117,14 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
     auto stage_x = [&](int xr, int g) {
         const int px = 4 * g + lq;
         const int xc = xcol0 + px;
-        const bool ok = (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW;
+        // channels past the tensor's (32-channel layers of the base-32 net fill half a tile) read zeros
+        const bool ok = (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW && it * 64 + 4 * l15 < k.ci_real;
         const float *src = p.X + ((size_t)((img * p.XH + xr) * p.XW + xc) * p.XC + p.xc0 + it * 64 + 4 * l15);
         GLDS16(ok ? src : zsrc, xs + (xr & (G::RING - 1)) * G::XSLOT + g * 1024);
     };
     auto stage_y = [&](int y, int buf, int g) {
         const int px = 4 * g + lq;
-        const bool ok = px < pwv;
+        const bool ok = px < pwv && jt * 64 + 4 * l15 < k.cj_real;
         const float *src = p.Y + ((size_t)((img * p.YH + y) * p.YW + x0 + px) * p.YC + p.yc0 + jt * 64 + 4 * l15);
         GLDS16(ok ? src : zsrc, ys + buf * G::YBUF + g * 1024);
     };
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
 // Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
 // even when the output is tiny (64x64x9) and the partition count is in the thousands.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, size_t pstride, int T, int Ci, int Cj,
+                                                           int ci_real, int cj_real,
                                                            float *__restrict__ out, long si, long sj, long st, float *__restrict__ db, int ndb)
 {
     const size_t nw = (size_t)T * Ci * Cj;
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
                 const int it = tile / ntj, jt = tile - it * ntj;
                 const int i = it * 64 + (wv >> 1) * 32 + ri + 8 * rq + 4 * (ln >> 5);
                 const int j = jt * 64 + (wv & 1) * 32 + (ln & 31);
-                out[i * si + j * sj + t * st] = v;
+                if (i < ci_real && j < cj_real) out[i * si + j * sj + t * st] = v;
             } else {
                 db[e - nw] = v;
             }
@@ -475,6 +478,7 @@ static void decompose(const WgradP &p, WgradK &k)
     k.nstrips = cdiv(wx, pw);
     k.ntile_i = p.Ci / 64;
     k.ntile_j = p.Cj / 64;
+    k.ci_real = k.cj_real = 0;             // set by launch_wgrad
     // Partitioning.  The pixels are cut into partitions (image x row-chunk x strip); `ngroups` workgroups per
     // channel tile share them round-robin, each accumulating its partitions in registers and writing ONE slab.
     // Choose rows-per-chunk r and ngroups to minimise  rounds(ngroups*ntile / resident slots) x ceil(nparts/ngroups) x r
@@ -529,8 +533,18 @@ static void decompose(const WgradP &p, WgradK &k)
     k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + (p.Ci > p.Cj ? p.Ci : p.Cj), 64);
 }
 
-size_t wgrad_slab_need(const WgradP &p)
+// whole 64-channel tiles: the kernels' unit; tensors with 32 channels (base-32 net) occupy half a tile
+static WgradP padded_tiles(const WgradP &p)
 {
+    WgradP q = p;
+    q.Ci = (p.Ci + 63) / 64 * 64;
+    q.Cj = (p.Cj + 63) / 64 * 64;
+    return q;
+}
+
+size_t wgrad_slab_need(const WgradP &p0)
+{
+    const WgradP p = padded_tiles(p0);
     WgradK k{};
     decompose(p, k);
     const size_t a = (size_t)k.ngroups * k.pstride * sizeof(float), b = wgradw_slab_need(p);
@@ -606,7 +620,11 @@ static int launch_wgrad_b(WgradK &k, hipStream_t st)
 
 int launch_wgrad(WgradP p, hipStream_t st)
 {
-    ARG_CHECK(p.Ci % 64 == 0 && p.Cj % 64 == 0 && p.Ci > 0 && p.Cj > 0, "wgrad: channel tiles must be multiples of 64 (Ci=%d Cj=%d)", p.Ci, p.Cj);
+    ARG_CHECK(p.Ci > 0 && p.Cj > 0 && p.Ci % 32 == 0 && p.Cj % 32 == 0, "wgrad: channel counts must be multiples of 32 (Ci=%d Cj=%d)", p.Ci, p.Cj);
+    if (p.math == 2) ARG_CHECK(p.Ci % 64 == 0 && p.Cj % 64 == 0, "wgrad (bf16): channel counts must be multiples of 64 (Ci=%d Cj=%d)", p.Ci, p.Cj);
+    const int ci_real = p.Ci, cj_real = p.Cj;
+    const bool winograd = p.math == 3 && wgradw_applicable(p);      // (decided on the tensors' own channel counts)
+    p = padded_tiles(p);
     ARG_CHECK(p.XC % 4 == 0 && p.YC % 4 == 0 && p.xc0 % 4 == 0 && p.yc0 % 4 == 0, "wgrad: channel pitch/offset must be multiples of 4");
     if (p.math == 2) ARG_CHECK(p.XC % 8 == 0 && p.YC % 8 == 0 && p.xc0 % 8 == 0 && p.yc0 % 8 == 0, "wgrad (bf16): channel pitch/offset must be multiples of 8");
     ARG_CHECK(p.ywin0 >= 0 && p.ywin1 <= p.YH && p.xwin0 >= 0 && p.xwin1 <= p.YW && p.ywin0 < p.ywin1 && p.xwin0 < p.xwin1, "wgrad: bad window");
@@ -616,10 +634,11 @@ int launch_wgrad(WgradP p, hipStream_t st)
     ARG_CHECK(p.math >= 0 && p.math <= 3, "wgrad: bad arithmetic mode %d", p.math);
     if (p.db) ARG_CHECK(p.ywin0 == 0 && p.xwin0 == 0 && p.ywin1 == p.YH && p.xwin1 == p.YW, "wgrad: fused bias gradient needs the full Y window");
     if (p.db && p.db_on_x) ARG_CHECK(p.stride == p.TY && p.stride == p.TX && p.xpad == 0, "wgrad: bias-on-X needs stride == taps (every X pixel staged exactly once)");
-    if (p.math == 3 && wgradw_applicable(p)) return launch_wgradw(p, st);     // Winograd F(3x3 <- 2x2) (wgradw.hip)
+    if (winograd) return launch_wgradw(p, st);     // Winograd F(3x3 <- 2x2) (wgradw.hip)
     WgradK k{};
     k.p = p;
     decompose(p, k);
+    k.ci_real = ci_real; k.cj_real = cj_real;
     const int nP = k.ngroups;                 // slabs to reduce
     const int T = p.TY * p.TX;
     const size_t need = (size_t)nP * k.pstride * sizeof(float);
@@ -632,12 +651,12 @@ int launch_wgrad(WgradP p, hipStream_t st)
         rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_b<2, 2, 2>(k, st);
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
-    const int ndb = p.db ? (p.db_on_x ? p.Ci : p.Cj) : 0;
+    const int ndb = p.db ? (p.db_on_x ? ci_real : cj_real) : 0;
     const size_t total = (size_t)T * p.Ci * p.Cj + ndb;
     size_t blocks = (total + 63) / 64;
     if (blocks > 16384) blocks = 16384;
     prof_begin(PK_REDUCE, "wgrad_reduce", st, 0.0, 0.0, (double)nP * k.pstride * 4.0 + (double)total * 4.0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, p.out, p.si, p.sj, p.st, p.db, ndb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, ci_real, cj_real, p.out, p.si, p.sj, p.st, p.db, ndb);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;

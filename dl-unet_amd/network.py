@@ -23,7 +23,7 @@ _BASE = 64          # hard-coded in the reference (network.py:23-58)
 
 def _layers(base=_BASE):
     """(name, kind, cin, cout, k) in the reference's declaration order; base = first-level width
-    (64 in the reference; 32 is the BASELINE config #5 inference variant)."""
+    (64 in the reference; 32 is the BASELINE config #5 variant)."""
     c = [base, 2 * base, 4 * base, 8 * base, 16 * base]
     return [
         ("conv11c", "conv", 1, c[0], 3), ("conv12c", "conv", c[0], c[0], 3),
@@ -133,7 +133,8 @@ class Unet(nn.Module):
 
     def __init__(self, base_ch=_BASE):
         """Unet() as in the reference (no arguments).  base_ch is an extension: 32 gives the half-width
-        net of BASELINE config #5 (inference only; the weight-gradient kernels need multiples of 64)."""
+        net of BASELINE config #5 (forward and backward; its 32-channel layers take the implicit-GEMM
+        kernels and half-filled weight-gradient tiles instead of the Winograd ones)."""
         super(Unet, self).__init__()
         self.base_ch = base_ch
         self._layer_table = _layers(base_ch)

@@ -108,8 +108,44 @@ def test_config5_overlap_tile_inference_base32(dev):
     xr = torch.from_numpy(aux_ref.normalise01(aux_ref.mirror_transform(imgs[0].double().numpy()))).float()[None, None]
     yr = torch_ref.unet_forward(p, xr)
     assert ((y.cpu() - yr).abs().max() / yr.abs().max()).item() < 2e-5
-    with pytest.raises(RuntimeError):                # training needs base_ch % 64 == 0 (weight-gradient tiles)
-        net(x).sum().backward()
+
+
+def test_base32_net_trains(dev):
+    """Unet(base_ch=32) (BASELINE config #5's width) through forward + backward: its 32-channel layers fill half a 64-channel
+    weight-gradient tile.  Every gradient against the torch restatement in fp64 on the HIP forward's own ReLU / pool branch is
+    not available for this width (the C oracle's same-branch entry point is), so: fp64 C oracle, same branch, all elements."""
+    import network
+    from oracle import oracle_c, parity, prng
+    import _hip
+    S, B, base = 188, 2, 32
+    params = prng.make_params(0, base=base)
+    x = prng.make_input(1, B, S)
+    dl = prng.make_cotangent(2, (B, 2, S - 184, S - 184))
+    net = network.Unet(base_ch=base)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    net = net.to(dev)
+    L = _hip.lib()
+    h = network._handle(0, base)
+    plist = [p.detach() for p in net._params()]
+    nbytes = h.workspace_bytes(B, S, True)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    logits = torch.empty(B, 2, S - 184, S - 184, device=dev)
+    ptab = _hip.ptr_table(plist)
+    _hip.check(L.unet_forward(h.h, ptab, _hip.ptr(torch.from_numpy(x).to(dev)), _hip.ptr(logits), B, S, _hip.ptr(ws), nbytes, 1, _hip.stream()), "fwd")
+    grads = [torch.empty_like(p) for p in plist]
+    _hip.check(L.unet_backward(h.h, ptab, _hip.ptr(torch.from_numpy(dl).to(dev)), _hip.ptr_table(grads), _hip.ptr(ws), nbytes, _hip.stream()), "bwd")
+    torch.cuda.synchronize()
+    masks, sels = parity.branch_of(h, ws, B, S)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref_logits, ref_grads = oracle_c.unet_fwd_bwd(p64, x.astype(np.float64), base=base, dlogits=dl.astype(np.float64), relu_masks=masks, pool_sel=sels)
+    assert parity.nerr(logits.cpu().numpy(), ref_logits) < 2e-5
+    for (k, _), g in zip(net.named_parameters(), grads):
+        assert parity.nerr(g.cpu().numpy(), ref_grads[k]) < 3e-4, k
+    # and through the module / autograd surface
+    net.zero_grad(set_to_none=True)
+    net(torch.from_numpy(x).to(dev)).backward(torch.from_numpy(dl).to(dev))
+    for p_, g in zip(net.parameters(), grads):
+        assert torch.equal(p_.grad, g)
 
 
 def test_config5_at_its_real_batch_crosses_2GiB(dev):
