@@ -263,7 +263,7 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # from tools/summarize_profiles.py (rocprofv3 --pmc passes)
             if os.path.exists(tpath) and B == B_PER_GPU:
-                traffic = json.load(open(tpath)).get("%s_hbm_mb_per_launch" % dom)
+                traffic = json.load(open(tpath)).get("math%d" % args.math, {}).get("%s_hbm_mb_per_launch" % dom)
                 traffic = traffic * 1e6 if traffic else None
             kname = {"wino": "wino32_f32_kernel (3x3 conv fwd / dgrad, Winograd F(2x2,3x3) on the fp32 MFMA)",
                      "igemm": "igemm kernels (conv fwd / dgrad / up-conv implicit GEMM)",

@@ -2,6 +2,7 @@
 """Condenses gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_*: run locally after gpurun."""
 import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
+math_mode = sys.argv[2] if len(sys.argv) > 2 else "3"          # arithmetic mode the profiled run used (bench.py --math)
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
@@ -66,5 +67,13 @@ for key, sub in DOM:
                      (sub, ns[key] / calls[key] / 1e6, calls[key],
                       "; bench.py HIP events: %.4f ms" % bench["roofline"]["avg_launch_ms"] if key == bench_dom else ""))
 open("profiles/%s_pmc_summary.md" % tag, "w").write("\n".join(lines) + "\n")
-json.dump(out, open("profiles/pmc_traffic.json", "w"))
+allm = {}
+if os.path.exists("profiles/pmc_traffic.json"):
+    try:
+        allm = json.load(open("profiles/pmc_traffic.json"))
+    except ValueError:
+        allm = {}
+allm = {k: v for k, v in allm.items() if k.startswith("math")}
+allm["math" + math_mode] = out
+json.dump(allm, open("profiles/pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines[-5:]))
