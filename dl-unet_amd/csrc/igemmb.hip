@@ -288,17 +288,27 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
         const int cur = ks & 1;
         if (ks + 1 < nk) { stage(cur ^ 1); advance(); }
         const unsigned char *sb = smem + cur * STAGE;
+        // fragments double-buffered in registers: the reads of k-step g+1 fly while the four MFMAs of g issue (left to itself
+        // the compiler reuses one register set and waits for every group's LDS latency in front of its MFMAs)
+        bf16x8 fa[2][2], fb[2][2];
+        auto read_frags = [&](int g, int q) {
+            const int pos = ((2 * g + lh) ^ swz) * 16;
+            fa[q][0] = *(const bf16x8 *)(sb + a_rd + pos);
+            fa[q][1] = *(const bf16x8 *)(sb + a_rd + 32 * 128 + pos);
+            fb[q][0] = *(const bf16x8 *)(sb + b_rd + pos);
+            fb[q][1] = *(const bf16x8 *)(sb + b_rd + 32 * 128 + pos);
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int pos = ((2 * g + lh) ^ swz) * 16;
-            const bf16x8 a0 = *(const bf16x8 *)(sb + a_rd + pos);
-            const bf16x8 a1 = *(const bf16x8 *)(sb + a_rd + 32 * 128 + pos);
-            const bf16x8 b0 = *(const bf16x8 *)(sb + b_rd + pos);
-            const bf16x8 b1 = *(const bf16x8 *)(sb + b_rd + 32 * 128 + pos);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            const int q = g & 1;
+            if (g + 1 < 4) read_frags(g + 1, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
     }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <type_traits>
 
 namespace unet {
 
@@ -329,8 +330,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.X, 0, k.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)p.Y, 0, k.ybytes, 0x00020000);
-    constexpr int OOB = (int)0x80000000;
+    static constexpr int OOB = (int)0x80000000;
 
+    // One copy of the whole partition loop per bias role (wave-uniform): the k loop's body must be straight-line code — a
+    // branch per tap made the compiler wait for every fragment right before its MFMA (LDS latency exposed 36 times per row) —
+    // and role branches INSIDE the row loop made the register allocator spill the accumulators around them.
+    auto run = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;        // 0: no bias sum, 1: db from the dz fragments, 2: db from the X fragments
     for (int P = grp; P < k.nparts; P += k.ngroups) {
     const int strip = P % k.nstrips;
     const int pc = P / k.nstrips;
@@ -384,18 +390,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
             if (y + 1 < yb) stage_step(y + 1, cur ^ 1, TY - S, S);
             const int xr0 = (y + p.oy0) * S - p.xpad;
             const unsigned char *yrow = ys + cur * G::YBUF + yoff;
-            for (int ks = 0; ks < nks; ++ks) {
-                const bf16x8 b = tr_frag(yrow + ks * (16 * 128));
-                if (do_bias) bsum += frag_sum(b);
+            const unsigned char *xrow[TY];
 #pragma unroll
-                for (int ty = 0; ty < TY; ++ty) {
-                    const unsigned char *xrow = xs + ((xr0 + ty) & (G::RING - 1)) * G::XSLOT + ks * (16 * 128);
+            for (int ty = 0; ty < TY; ++ty) xrow[ty] = xs + ((xr0 + ty) & (G::RING - 1)) * G::XSLOT;
+            // Software pipeline in place: as soon as tap t's MFMA of k-step ks has issued, its fragment register is refilled
+            // with the fragment of k-step ks+1 (the last k-step re-reads itself: branch-free), so 9 reads are always in flight
+            // behind the MFMAs and a second fragment set is not needed.
+            {
+                bf16x8 a[T], b;
+                b = tr_frag(yrow);
 #pragma unroll
-                    for (int tx = 0; tx < TX; ++tx) {
-                        const bf16x8 a = tr_frag(xrow + xoff[tx]);
-                        if (do_xbias) bsum += frag_sum(a);
-                        acc[ty * TX + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * TX + tx], 0, 0, 0);
-                    }
+                for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx) a[ty * TX + tx] = tr_frag(xrow[ty] + xoff[tx]);
+                for (int ks = 0; ks < nks; ++ks) {
+                    const int kn = (ks + 1 < nks ? ks + 1 : ks) * (16 * 128);
+                    const bf16x8 bn = tr_frag(yrow + kn);
+                    if (ROLE == 1) bsum += frag_sum(b);
+#pragma unroll
+                    for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < TX; ++tx) {
+                            const int t = ty * TX + tx;
+                            if (ROLE == 2) bsum += frag_sum(a[t]);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b, acc[t], 0, 0, 0);
+                            a[t] = tr_frag(xrow[ty] + kn + xoff[tx]);
+                            __builtin_amdgcn_sched_barrier(0);      // keep the refill BEHIND its MFMA: hoisted, it needs a second register set
+                        }
+                    b = bn;
                 }
             }
             __syncthreads();
@@ -403,6 +425,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
     }
 
     }   // partitions of this workgroup
+    };
+    if (do_xbias) run(std::integral_constant<int, 2>{});
+    else if (do_bias) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
 
     float *slab = p.slab + (size_t)grp * k.pstride;
     if (do_bias || do_xbias) {
