@@ -78,22 +78,28 @@ __device__ __forceinline__ void igemm_epilogue_store(const IgemmP &p, f32x16 (&a
         }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
+            // +add / ReLU' mask operands first: their latency runs under the LDS transpose
+            size_t o[4];
+            f32x4 ta[4], tk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (size_t)rowoff[wm * 64 + tm * 32 + rrow + 8 * k] + (size_t)coloff;
+            if (p.add) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ta[k] = *(const f32x4 *)(p.add + o[k]);
+            }
+            if (p.mask) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tk[k] = *(const f32x4 *)(p.mask + o[k]);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_PITCH + l31] = acc[tm][tn][r] + bv;
             f32x4 v[4];
-            size_t o[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = *(const f32x4 *)(patch + (rrow + 8 * k) * EPI_PITCH + 4 * cg);
-                o[k] = (size_t)rowoff[wm * 64 + tm * 32 + rrow + 8 * k] + (size_t)coloff;
-            }
+            for (int k = 0; k < 4; ++k) v[k] = *(const f32x4 *)(patch + (rrow + 8 * k) * EPI_PITCH + 4 * cg);
             if (p.add) {
-                f32x4 t[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = *(const f32x4 *)(p.add + o[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += t[k];
+                for (int k = 0; k < 4; ++k) v[k] += ta[k];
             }
             if (p.relu) {
 #pragma unroll
@@ -104,13 +110,10 @@ __device__ __forceinline__ void igemm_epilogue_store(const IgemmP &p, f32x16 (&a
                 }
             }
             if (p.mask) {
-                f32x4 t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = *(const f32x4 *)(p.mask + o[k]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[k][c] = t[k][c] > 0.f ? v[k][c] : 0.f;
+                    for (int c = 0; c < 4; ++c) v[k][c] = tk[k][c] > 0.f ? v[k][c] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)

@@ -258,10 +258,13 @@ struct WgradBGeom {
     static constexpr int T = TY * TX;
     static constexpr int XPX = S == 1 ? (PWB + TX - 1 + 7) / 8 * 8 : TX * PWB;    // staged X pixel positions per row
     static constexpr int XG = XPX / 8, YG = PWB / 8;                               // LDS-DMA instructions (8 pixels) per row
-    static constexpr int RING = 4;
+    // one row step of prefetch: a second one (5-slot X ring, 3 dz buffers, counted vmcnt) was measured 5 % slower with in-kernel
+    // cycle stamps - the wait + barrier share is 3 % of a workgroup's time, what costs is the LDS-DMA issue itself (below)
+    static constexpr int RING = TY + S, NY = 2;
     static constexpr int XSLOT = XPX * 128, YBUF = PWB * 128;
-    static constexpr int LDS = RING * XSLOT + 2 * YBUF;
-    static_assert(TY + S <= RING, "ring too small");
+    static constexpr int LDS = RING * XSLOT + NY * YBUF;
+    static constexpr int NI = (S * XG + YG + 3) / 4;                  // LDS-DMA instructions per wave and steady-state row step
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     static_assert(S == 1 || (S == 2 && TX == 2), "stride-2 staging assumes 2 taps per row");
 };
 
@@ -278,6 +281,13 @@ __device__ __forceinline__ float frag_sum(const bf16x8 &v)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += (float)v[j];
     return s;
+}
+
+// (a plain function: with a run-time scalar offset the builtin, used directly inside the kernel's nested lambdas, makes the host
+//  pass drop the kernel's stub without a diagnostic)
+__device__ __forceinline__ void wgb_dma16(__amdgpu_buffer_rsrc_t r, unsigned char *lds, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
 }
 
 template <int TY, int TX, int S>
@@ -349,14 +359,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
     const int nks = (pwv + 15) >> 4;
     const int xcol0 = (x0 + p.ox0) * S - p.xpad;
 
-    auto stage_x = [&](int xr, int g) {
+    auto stage_x = [&](int xr, int slot, int g) {
         const int pos = 8 * g + d_px;
         int xc; bool ok;
         if (S == 1) { xc = xcol0 + pos; ok = true; }
         else { const int tx = pos / PWB, px = pos - tx * PWB; xc = xcol0 + 2 * px + tx; ok = px < pwv; }
         ok = ok && (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW;
         const int off = (((img * p.XH + xr) * p.XW + xc) * p.XC + p.xc0 + it * 64 + d_c * 8) * 2;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(xs + (xr & (G::RING - 1)) * G::XSLOT + g * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(xs + slot * G::XSLOT + g * 1024), 16,
                                                  ok ? off : OOB, 0, 0, 0);
     };
     auto stage_y = [&](int y, int buf, int g) {
@@ -369,15 +379,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
     // last needed pixel are skipped (their LDS content is never read: k-steps stop at nks).
     const int xg_used = S == 1 ? ((16 * nks + TX - 1 + 7) >> 3) : G::XG;
     const int yg_used = 2 * nks;
-    auto stage_step = [&](int y, int buf, int first_row, int nrows) {
+    // step j (row ya + j) reads the X rows j*S .. j*S + TY-1 of the chunk (ring slot = row index mod RING) and Y buffer j mod NY
+    auto stage_step = [&](int y, int j, int first_row, int nrows) {
         const int xr_base = (y + p.oy0) * S - p.xpad;
         const int nx = nrows * xg_used;
+        const int buf = j % G::NY;
         for (int e = wave; e < nx + yg_used; e += 4) {
             if (e < nx) {
                 const int rr = e / xg_used;
-                stage_x(xr_base + first_row + rr, e - rr * xg_used);
+                stage_x(xr_base + first_row + rr, (j * S + first_row + rr) % G::RING, e - rr * xg_used);
             } else {
                 stage_y(y, buf, e - nx);
+            }
+        }
+    };
+    // LDS-DMA instructions this wave issues for one steady-state step (S new X rows + the Y row)
+    const int n_items = S * xg_used + yg_used;
+    // The steady-state step's items of this wave, worked out once per partition: everything that depends on the lane (column,
+    // channel chunk, column validity) sits in the buffer instruction's vector offset, the row goes into its scalar offset -
+    // a step then issues its LDS-DMA with no per-lane address arithmetic.  In-kernel cycle stamps (8 x 280^2 x 128 -> 128): the
+    // generic stage_step above (an integer division and ~20 VALU instructions per item) held a wave 33 % of its time, this
+    // 19 % - what is left is the texture-address unit taking the workgroups' 17 one-KiB instructions per row (~200 cycles per
+    // instruction seen from the issuing wave, all eight waves of the CU queueing behind each other right after a barrier).
+    // Spreading the items over the k loop instead (one per k-step) costs more than it hides: the branches cut the loop's
+    // software pipeline (weight-gradient family 2.87 -> 3.93 ms per step).
+    int iv[G::NI], il[G::NI], irr[G::NI];
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        const int e = wave + 4 * i;
+        iv[i] = OOB; il[i] = 0; irr[i] = -1;
+        if (e < S * xg_used) {
+            const int rr = (S == 2 && e >= xg_used) ? 1 : 0;
+            const int g = e - rr * xg_used;
+            const int pos = 8 * g + d_px;
+            int xc; bool ok;
+            if (S == 1) { xc = xcol0 + pos; ok = true; }
+            else { const int tx = pos / PWB, px = pos - tx * PWB; xc = xcol0 + 2 * px + tx; ok = px < pwv; }
+            ok = ok && (unsigned)xc < (unsigned)p.XW;
+            iv[i] = ok ? (xc * p.XC + p.xc0 + it * 64 + d_c * 8) * 2 : OOB;
+            il[i] = g * 1024; irr[i] = rr;
+        } else if (e < n_items) {
+            const int g = e - S * xg_used;
+            const int px = 8 * g + d_px;
+            iv[i] = px < pwv ? ((x0 + px) * p.YC + p.yc0 + jt * 64 + d_c * 8) * 2 : OOB;
+            il[i] = g * 1024;
+        }
+    }
+    auto stage_fast = [&](int y, int j) {
+        const int xr_base = (y + p.oy0) * S - p.xpad + (TY - S);
+        unsigned char *yb_ = ys + (j % G::NY) * G::YBUF;
+        const int ysoff = ((img * p.YH + y) * p.YW) * p.YC * 2;
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            if (wave + 4 * i < n_items) {
+                if (irr[i] >= 0) {
+                    const int xr = xr_base + irr[i];
+                    const bool rok = (unsigned)xr < (unsigned)p.XH;
+                    unsigned char *dst = xs + ((j * S + (TY - S) + irr[i]) % G::RING) * G::XSLOT + il[i];
+                    wgb_dma16(rs_x, dst, rok ? iv[i] : OOB, rok ? ((img * p.XH + xr) * p.XW) * p.XC * 2 : 0);
+                } else {
+                    wgb_dma16(rs_y, yb_ + il[i], iv[i], ysoff);
+                }
             }
         }
     };
@@ -385,14 +447,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
     if (ya < yb) {
         stage_step(ya, 0, 0, TY);
         __syncthreads();
-        for (int y = ya; y < yb; ++y) {
-            const int cur = (y - ya) & 1;
-            if (y + 1 < yb) stage_step(y + 1, cur ^ 1, TY - S, S);
-            const int xr0 = (y + p.oy0) * S - p.xpad;
-            const unsigned char *yrow = ys + cur * G::YBUF + yoff;
+        for (int y = ya, j = 0; y < yb; ++y, ++j) {
+            if (y + 1 < yb) stage_fast(y + 1, j + 1);
+            const unsigned char *yrow = ys + (j % G::NY) * G::YBUF + yoff;
             const unsigned char *xrow[TY];
 #pragma unroll
-            for (int ty = 0; ty < TY; ++ty) xrow[ty] = xs + ((xr0 + ty) & (G::RING - 1)) * G::XSLOT;
+            for (int ty = 0; ty < TY; ++ty) xrow[ty] = xs + ((j * S + ty) % G::RING) * G::XSLOT;
             // Software pipeline in place: as soon as tap t's MFMA of k-step ks has issued, its fragment register is refilled
             // with the fragment of k-step ks+1 (the last k-step re-reads itself: branch-free), so 9 reads are always in flight
             // behind the MFMAs and a second fragment set is not needed.
@@ -420,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
                     b = bn;
                 }
             }
-            __syncthreads();
+            __syncthreads();            // the next step's rows have landed (vmcnt(0)); every wave is done with this step's slots
         }
     }
 

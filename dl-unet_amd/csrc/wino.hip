@@ -338,8 +338,6 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
             load_v((s + 1) & 1);
         }
     }
-    __syncthreads();
-
     // ---- epilogue: staging[256 rows = tile*4 + 2*py + px][32 n] in the U ring | rowoff[256] | flags[256]
     float *stg = (float *)(smem + W32_UBASE);
     unsigned *rowoff = (unsigned *)(smem + W32_LDS);
@@ -362,6 +360,36 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         rowoff[tid] = off;
         const bool inwin = (p.rw1 > p.rw0) && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
         rflag[tid] = (ok ? 0 : 1) | (inwin ? 2 : 0);
+    }
+    __syncthreads();                 // K loop done in every wave (the staging aliases the U ring); row tables visible
+
+    // destination offsets of this thread's 2 x 4 rows, and the +add / ReLU' mask operands: issued now, their latency runs
+    // under the output transform
+    const bool relu_win = p.rw1 > p.rw0;
+    const int c4 = tid & 7;
+    const int ncol = n0 + 4 * c4;
+    size_t eo[2][4];
+    unsigned char efl[2][4];
+    f32x4 eadd[2][4], emask[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = (h * 32 + (tid >> 3)) * 4 + u;                 // the four pixels of one tile
+            eo[h][u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
+            efl[h][u] = rflag[row];
+        }
+    if (p.add) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) eadd[h][u] = *(const f32x4 *)(p.add + eo[h][u]);
+    }
+    if (p.mask) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emask[h][u] = *(const f32x4 *)(p.mask + eo[h][u]);
     }
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
@@ -387,58 +415,43 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         }
     }
     __syncthreads();
-    const bool relu_win = p.rw1 > p.rw0;
-    const int c4 = tid & 7;
-    const int ncol = n0 + 4 * c4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = p.bias[p.cout ? n % p.cout : n]; }
     }
 #pragma unroll
-    for (int it = 0; it < 8; it += 4) {
+    for (int h = 0; h < 2; ++h) {
         f32x4 v[4];
-        size_t o[4];
-        unsigned char fl[4];
+        const int tloc = h * 32 + (tid >> 3);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int tloc = (it >> 2) * 32 + (tid >> 3);
-            const int row = tloc * 4 + u;                                  // the four pixels of one tile
+        for (int u = 0; u < 4; ++u)
             v[u] = *(const f32x4 *)(stg + tloc * 128 + (u ^ (tloc & 1)) * 32 + ((4 * c4) ^ (((tloc >> 2) & 1) << 4))) + bv;
-            o[u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
-            fl[u] = rflag[row];
-        }
         if (p.add) {
-            f32x4 t[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.add + o[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] += t[u];
+            for (int u = 0; u < 4; ++u) v[u] += eadd[h][u];
         }
         if (p.relu) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool defer = relu_win && (fl[u] & 2);
+                const bool defer = relu_win && (efl[h][u] & 2);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] > 0.f || defer) ? v[u][c] : 0.f;
             }
         }
         if (p.mask) {
-            f32x4 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = *(const f32x4 *)(p.mask + o[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[u][c] = t[u][c] > 0.f ? v[u][c] : 0.f;
+                for (int c = 0; c < 4; ++c) v[u][c] = emask[h][u][c] > 0.f ? v[u][c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (!(fl[u] & 1)) *(f32x4 *)(p.dst + o[u]) = v[u];
+            if (!(efl[h][u] & 1)) *(f32x4 *)(p.dst + eo[h][u]) = v[u];
         if (p.pool_dst) {
             // fused 2x2 max-pool (network.py:132-150): a Winograd tile IS one pooling window and the linear tile index
             // is the pooled pixel index (launch_wino checks even extents)
-            const int T = T0 + (it >> 2) * 32 + (tid >> 3);
+            const int T = T0 + tloc;
             if (T < k.MT) {
                 f32x4 m;
 #pragma unroll
