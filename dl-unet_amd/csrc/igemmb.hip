@@ -16,7 +16,9 @@
 // for all 9 taps, 3x less L2 -> LDS traffic, one 512-thread workgroup per CU) was built, was correct, and was measured
 // interleaved in one process against this kernel on every 3x3 layer: 0.93x-1.35x the time (faster only on conv42c) — its
 // single workgroup per CU exposes the halo prologue and the epilogue, and its 8 lockstep waves all read their fragments right
-// after each barrier.  It was removed; DESIGN.md section 4c has the numbers.
+// after each barrier.  It was removed; DESIGN.md section 4c has the numbers.  Also measured and dropped: issuing the next stage's
+// LDS-DMA in quarters between the MFMA groups instead of in one burst after the barrier (+6 % time), a second stage of prefetch,
+// and 32-channel K steps with 64-byte LDS rows (tools/ldsdma_depth.hip: the L2 -> LDS path moves 64-byte pieces at 2/3 the rate).
 #include "common.hpp"
 #include "igemm_epilogue.hpp"
 #include <cstdio>
