@@ -38,7 +38,7 @@ constexpr int PWMAX = 32;     // pixels per strip (MFMA K = pixel pairs)
 struct WgradK {               // kernel-side copy with the derived decomposition
     WgradP p;
     int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
-    int xbytes, ybytes;                // bf16 kernel: buffer-descriptor sizes of X and Y
+    int xbytes, ybytes;                // buffer-descriptor sizes of X and Y (bytes; the buffer paths need both below 2 GiB)
     int ci_real, cj_real;              // channel counts of the tensors; p.Ci / p.Cj are these rounded up to whole 64-channel tiles
     int nparts, ngroups;               // pixel partitions, and workgroups per channel tile that share them
     size_t pstride;                    // floats per partition in the slab: T*Ci*Cj weights + Cj bias partials
@@ -54,10 +54,20 @@ struct WgradGeom {
     static constexpr int XSLOT = XPX * 256;                           // bytes: 64 channels fp32 per pixel
     static constexpr int YBUF = PWMAX * 256;
     static constexpr int LDS = RING * XSLOT + 2 * YBUF;
+    static constexpr int NI = (S * XGROUPS + YGROUPS + 3) / 4;       // LDS-DMA instructions per wave and steady-state row step
     static_assert(TY + S <= RING, "ring too small");
 };
 
-template <int TY, int TX, int S, int NSPLIT>   // NSPLIT 0: exact fp32 MFMA; 3: bf16x3 split of fp32 operands (see igemmx.hip)
+// (a plain function: with a run-time scalar offset the builtin, used directly inside a kernel's nested lambdas, makes the host
+//  pass drop the kernel's stub without a diagnostic)
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t r, unsigned char *lds, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
+}
+
+// NSPLIT 0: exact fp32 MFMA; 3: bf16x3 split of fp32 operands (see igemmx.hip).  BUF: the steady-state row step stages through
+// buffer descriptors with its items worked out once per partition (tensors below 2 GiB); else global_load_lds per item.
+template <int TY, int TX, int S, int NSPLIT, bool BUF>
 __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void wgrad_f32_kernel(const WgradK k)
 {
     using G = WgradGeom<TY, TX, S>;
@@ -101,6 +111,9 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
     const int l31 = lane & 31, lh = lane >> 5;
     const int a_lane = (wi * 32 + l31) * 4;      // byte offset of this lane's X channel within a pixel
     const int b_lane = (wj * 32 + l31) * 4;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.X, 0, BUF ? k.xbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)p.Y, 0, BUF ? k.ybytes : 0, 0x00020000);
+    static constexpr int OOB = (int)0x80000000;
 
     for (int P = grp; P < k.nparts; P += k.ngroups) {
     const int strip = P % k.nstrips;
@@ -143,12 +156,57 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
         }
     };
 
+    // BUF: this wave's items of a steady-state step (S new X rows + the Y row), worked out once per partition - the lane part
+    // (column, channel, validity) is the instruction's vector offset, the row its scalar offset, so a step issues its LDS-DMA
+    // without per-lane address arithmetic (the generic stage_step costs an integer division and ~20 VALU per item; in the
+    // bf16 twin of this kernel that was a third of a workgroup's time)
+    int iv[G::NI], il[G::NI], irr[G::NI];
+    if (BUF) {
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            const int e = wave + 4 * i;
+            iv[i] = OOB; il[i] = 0; irr[i] = -1;
+            if (e < S * G::XGROUPS) {
+                const int rr = (S == 2 && e >= G::XGROUPS) ? 1 : 0;
+                const int g = e - rr * G::XGROUPS;
+                const int xc = xcol0 + 4 * g + lq;
+                const bool ok = (unsigned)xc < (unsigned)p.XW && it * 64 + 4 * l15 < k.ci_real;
+                iv[i] = ok ? (xc * p.XC + p.xc0 + it * 64 + 4 * l15) * 4 : OOB;
+                il[i] = g * 1024; irr[i] = rr;
+            } else if (e < S * G::XGROUPS + G::YGROUPS) {
+                const int g = e - S * G::XGROUPS;
+                const int px = 4 * g + lq;
+                const bool ok = px < pwv && jt * 64 + 4 * l15 < k.cj_real;
+                iv[i] = ok ? ((x0 + px) * p.YC + p.yc0 + jt * 64 + 4 * l15) * 4 : OOB;
+                il[i] = g * 1024;
+            }
+        }
+    }
+    auto stage_fast = [&](int y, int buf) {
+        const int xr_base = (y + p.oy0) * S - p.xpad + (TY - S);
+        const int ysoff = ((img * p.YH + y) * p.YW) * p.YC * 4;
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            if (wave + 4 * i < S * G::XGROUPS + G::YGROUPS) {
+                if (irr[i] >= 0) {
+                    const int xr = xr_base + irr[i];
+                    const bool rok = (unsigned)xr < (unsigned)p.XH;
+                    wg_dma16(rs_x, xs + (xr & (G::RING - 1)) * G::XSLOT + il[i], rok ? iv[i] : OOB, rok ? ((img * p.XH + xr) * p.XW) * p.XC * 4 : 0);
+                } else {
+                    wg_dma16(rs_y, ys + buf * G::YBUF + il[i], iv[i], ysoff);
+                }
+            }
+        }
+    };
+
     if (ya < yb) {
         stage_step(ya, 0, 0, TY);                // prologue: all TY rows + Y row
         __syncthreads();
         for (int y = ya; y < yb; ++y) {
             const int cur = (y - ya) & 1;
-            if (y + 1 < yb) stage_step(y + 1, cur ^ 1, TY - S, S);   // rows new to the next step
+            if (y + 1 < yb) {                    // rows new to the next step
+                if (BUF) stage_fast(y + 1, cur ^ 1); else stage_step(y + 1, cur ^ 1, TY - S, S);
+            }
             const int xr0 = (y + p.oy0) * S - p.xpad;
             if (do_bias) {
                 const float *yb_ = (const float *)(ys + cur * G::YBUF) + bch;
@@ -662,12 +720,19 @@ double wgrad_alg_bytes(const WgradP &p)
 }
 
 template <int TY, int TX, int S, int NSPLIT>
-static int launch_wgrad_t(const WgradK &k, hipStream_t st)
+static int launch_wgrad_t(WgradK &k, hipStream_t st)
 {
     using G = WgradGeom<TY, TX, S>;
-    static bool attr_done[64] = {false};
-    auto kern = wgrad_f32_kernel<TY, TX, S, NSPLIT>;
-    if (int rc_ = ensure_dynamic_lds((const void *)kern, G::LDS, attr_done)) return rc_;
+    static bool attr_done[64] = {false}, attr_done_b[64] = {false};
+    // buffer-descriptor staging needs both tensors below 2 GiB (32-bit offsets, the out-of-range marker); larger ones and
+    // unet_set_lds_dma(0) take the global_load_lds instantiation
+    const size_t xb = (size_t)k.p.NB * k.p.XH * k.p.XW * k.p.XC * 4, yb = (size_t)k.p.NB * k.p.YH * k.p.YW * k.p.YC * 4;
+    // (not for the exact-fp32 3x3 instantiation: at its three waves per SIMD the item registers would spill)
+    constexpr bool CAN_BUF = !(TY * TX == 9 && NSPLIT == 0);
+    const bool buf = CAN_BUF && get_lds_dma_mode() != 0 && xb < 0x7FFFFFFFull && yb < 0x7FFFFFFFull;
+    k.xbytes = buf ? (int)xb : 0; k.ybytes = buf ? (int)yb : 0;
+    auto kern = buf ? wgrad_f32_kernel<TY, TX, S, NSPLIT, CAN_BUF> : wgrad_f32_kernel<TY, TX, S, NSPLIT, false>;
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, G::LDS, buf ? attr_done_b : attr_done)) return rc_;
     char tag[96];
     snprintf(tag, sizeof(tag), "wgrad<%d;%d;%d;split%d> Ci=%d Cj=%d Y=%dx%d win=%d parts=%d pw=%d rows=%d groups=%d", TY, TX, S, NSPLIT, k.p.Ci, k.p.Cj, k.p.YH, k.p.YW,
              k.p.ywin1 - k.p.ywin0, k.nparts, k.pw, k.rows_per_chunk, k.ngroups);
