@@ -564,46 +564,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
 // out[i*si + j*sj + t*st] = sum_P slab_P(t,i,j)  and  db[j] = sum_P slab[P][T*Ci*Cj + j], in a fixed order.
 // Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
 // even when the output is tiny (64x64x9) and the partition count is in the thousands.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, size_t pstride, int T, int Ci, int Cj,
-                                                           int ci_real, int cj_real,
-                                                           float *__restrict__ out, long si, long sj, long st, float *__restrict__ db, int ndb)
+// A thread sums 4 consecutive outputs (16-byte loads: 1 KiB per wave instruction) over the slabs of its partition group;
+// PG groups (4, or 16 when the launch has many slabs: few outputs, e.g. 64 x 64 x 9, and thousands of partitions) are combined
+// through LDS in a fixed order.
+template <int PG>
+__global__ __launch_bounds__(64 * PG) void wgrad_reduce_kernel(const float *__restrict__ slab, int nP, size_t pstride, int T, int Ci, int Cj,
+                                                               int ci_real, int cj_real,
+                                                               float *__restrict__ out, long si, long sj, long st, float *__restrict__ db, int ndb)
 {
     const size_t nw = (size_t)T * Ci * Cj;
-    const size_t total = nw + (db ? (size_t)ndb : 0);
+    const size_t total = nw + (db ? (size_t)ndb : 0);          // nw, ndb and pstride are multiples of 4
     const int lane_e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    __shared__ float red[256];
-    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
-        const size_t e = base + lane_e;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    __shared__ f32x4 red[PG][64];
+    for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {
+        const size_t e = base + 4 * lane_e;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
         if (e < total) {
             const float *src = slab + e;
             int P = grp;
-            for (; P + 12 < nP; P += 16) {
-                s0 += src[(size_t)P * pstride];
-                s1 += src[(size_t)(P + 4) * pstride];
-                s2 += src[(size_t)(P + 8) * pstride];
-                s3 += src[(size_t)(P + 12) * pstride];
+            for (; P + 3 * PG < nP; P += 4 * PG) {
+                s0 += *(const f32x4 *)(src + (size_t)P * pstride);
+                s1 += *(const f32x4 *)(src + (size_t)(P + PG) * pstride);
+                s2 += *(const f32x4 *)(src + (size_t)(P + 2 * PG) * pstride);
+                s3 += *(const f32x4 *)(src + (size_t)(P + 3 * PG) * pstride);
             }
-            for (; P < nP; P += 4) s0 += src[(size_t)P * pstride];
+            for (; P < nP; P += PG) s0 += *(const f32x4 *)(src + (size_t)P * pstride);
         }
-        red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        red[grp][lane_e] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (grp == 0 && e < total) {
-            const float v = (red[lane_e] + red[lane_e + 64]) + (red[lane_e + 128] + red[lane_e + 192]);
+            f32x4 v = red[0][lane_e];
+#pragma unroll
+            for (int g = 1; g < PG; ++g) v += red[g][lane_e];
             if (e < nw) {
-                // decode the register-order slab index (see wgrad_f32_kernel): [tile][wave][t][r/4][lane][r%4]
-                const int ri = (int)(e & 3), ln = (int)((e >> 2) & 63), rq = (int)((e >> 8) & 3);
+                // decode the register-order slab index (see wgrad_f32_kernel): [tile][wave][t][r/4][lane][r%4]; e % 4 == 0
+                const int ln = (int)((e >> 2) & 63), rq = (int)((e >> 8) & 3);
                 const size_t hi = e >> 10;
                 const int t = (int)(hi % T);
                 const int wv = (int)((hi / T) & 3);
                 const int tile = (int)(hi / T / 4);
                 const int ntj = Cj >> 6;
                 const int it = tile / ntj, jt = tile - it * ntj;
-                const int i = it * 64 + (wv >> 1) * 32 + ri + 8 * rq + 4 * (ln >> 5);
+                const int i0 = it * 64 + (wv >> 1) * 32 + 8 * rq + 4 * (ln >> 5);
                 const int j = jt * 64 + (wv & 1) * 32 + (ln & 31);
-                if (i < ci_real && j < cj_real) out[i * si + j * sj + t * st] = v;
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri)
+                    if (i0 + ri < ci_real && j < cj_real) out[(i0 + ri) * si + j * sj + t * st] = v[ri];
             } else {
-                db[e - nw] = v;
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri)
+                    if (e - nw + ri < (size_t)ndb) db[e - nw + ri] = v[ri];
             }
         }
         __syncthreads();
@@ -804,10 +814,14 @@ int launch_wgrad(WgradP p, hipStream_t st)
     if (rc) return rc;
     const int ndb = p.db ? (p.db_on_x ? ci_real : cj_real) : 0;
     const size_t total = (size_t)T * p.Ci * p.Cj + ndb;
-    size_t blocks = (total + 63) / 64;
+    size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
+    ARG_CHECK(k.pstride % 4 == 0 && ndb % 4 == 0 && ((uintptr_t)p.slab & 15) == 0, "wgrad: the reduce needs 16-byte aligned slabs");
     prof_begin(PK_REDUCE, "wgrad_reduce", st, 0.0, 0.0, (double)nP * k.pstride * 4.0 + (double)total * 4.0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, ci_real, cj_real, p.out, p.si, p.sj, p.st, p.db, ndb);
+    if (nP >= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)blocks), dim3(1024), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, ci_real, cj_real, p.out, p.si, p.sj, p.st, p.db, ndb);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.slab, nP, k.pstride, T, p.Ci, p.Cj, ci_real, cj_real, p.out, p.si, p.sj, p.st, p.db, ndb);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;

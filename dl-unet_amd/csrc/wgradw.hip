@@ -320,29 +320,44 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
 }
 
 // out[(i0+i)*si + (j0+j)*sj + t*st] = (G^T (sigma (.) sum_parts dU) G)[t],  db[j] = sum_parts
-__global__ __launch_bounds__(256) void wgradw_reduce_kernel(const float *__restrict__ slab, int nsplit, size_t pstride, int ntile_j,
+// PG part groups of 64 threads (4, or 16 for the launches with one to four channel tiles: 64 blocks per tile are too few
+// to keep the memory system busy with 4 waves each)
+template <int PG>
+__global__ __launch_bounds__(64 * PG) void wgradw_reduce_kernel(const float *__restrict__ slab, int nsplit, size_t pstride, int ntile_j,
                                                             float *__restrict__ out, long si, long sj, long st,
                                                             float *__restrict__ db, int db_c0)
 {
-    // block = one (tile, ci); 64 threads along cj x 4 part groups
+    // block = one (tile, ci); 64 threads along cj x PG part groups
     const int tile = blockIdx.x >> 6, i = blockIdx.x & 63;
     const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const float *src = slab + (size_t)tile * nsplit * pstride + (size_t)i * 64 + j;
     float m[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) m[x] = 0.f;
-    for (int P = grp; P < nsplit; P += 4) {
+    for (int P = grp; P < nsplit; P += PG) {
         const float *s = src + (size_t)P * pstride;
 #pragma unroll
         for (int x = 0; x < 16; ++x) m[x] += s[x * 4096];
     }
-    __shared__ float red[4][16][64];
+    __shared__ float red[PG][4][64];
+    // four passes of four xi through a 4 (16) KiB buffer
 #pragma unroll
-    for (int x = 0; x < 16; ++x) red[grp][x][j] = m[x];
-    __syncthreads();
+    for (int xq = 0; xq < 4; ++xq) {
+        if (xq) __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 4; ++x) red[grp][x][j] = m[4 * xq + x];
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                float v = red[0][x][j];
+#pragma unroll
+                for (int g = 1; g < PG; ++g) v += red[g][x][j];
+                m[4 * xq + x] = v;
+            }
+        }
+    }
     if (grp == 0) {
-#pragma unroll
-        for (int x = 0; x < 16; ++x) m[x] = (red[0][x][j] + red[1][x][j]) + (red[2][x][j] + red[3][x][j]);
         m[3] = -m[3]; m[7] = -m[7]; m[11] = -m[11]; m[12] = -m[12]; m[13] = -m[13]; m[14] = -m[14];
         // r = G^T m (3x4), dg = r G (3x3);  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
         float r[3][4];
@@ -366,10 +381,15 @@ __global__ __launch_bounds__(256) void wgradw_reduce_kernel(const float *__restr
         __syncthreads();
         const int jt = tile % ntile_j;
         float v = 0.f;
-        for (int P = grp; P < nsplit; P += 4) v += slab[((size_t)tile * nsplit + P) * pstride + 16 * 64 * 64 + j];
+        for (int P = grp; P < nsplit; P += PG) v += slab[((size_t)tile * nsplit + P) * pstride + 16 * 64 * 64 + j];
         red[grp][0][j] = v;
         __syncthreads();
-        if (grp == 0) db[db_c0 + jt * 64 + j] = (red[0][0][j] + red[1][0][j]) + (red[2][0][j] + red[3][0][j]);
+        if (grp == 0) {
+            float t = red[0][0][j];
+#pragma unroll
+            for (int g = 1; g < PG; ++g) t += red[g][0][j];
+            db[db_c0 + jt * 64 + j] = t;
+        }
     }
 }
 
@@ -443,8 +463,12 @@ int launch_wgradw(const WgradP &p, hipStream_t st)
     prof_end(st);
     HIP_TRY(hipGetLastError());
     prof_begin(PK_REDUCE, "wgradw_reduce", st, 0.0, 0.0, (double)ntile * k.nsplit * k.pstride * 4.0 + 9.0 * p.Ci * p.Cj * 4.0);
-    hipLaunchKernelGGL(wgradw_reduce_kernel, dim3(ntile * 64), dim3(256), 0, st, p.slab, k.nsplit, k.pstride, k.ntile_j,
-                       p.out, p.si, p.sj, p.st, p.db, p.yc0);
+    if (ntile <= 4 && k.nsplit >= 32)
+        hipLaunchKernelGGL(wgradw_reduce_kernel<16>, dim3(ntile * 64), dim3(1024), 0, st, p.slab, k.nsplit, k.pstride, k.ntile_j,
+                           p.out, p.si, p.sj, p.st, p.db, p.yc0);
+    else
+        hipLaunchKernelGGL(wgradw_reduce_kernel<4>, dim3(ntile * 64), dim3(256), 0, st, p.slab, k.nsplit, k.pstride, k.ntile_j,
+                           p.out, p.si, p.sj, p.st, p.db, p.yc0);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
