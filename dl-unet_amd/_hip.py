@@ -44,6 +44,7 @@ _SIGS = {
     "unet_activation_bytes": (C.c_int, [vp]),
     "unet_debug_buffer": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "unet_profile_enable": (C.c_int, [C.c_int]),
+    "unet_profile_select": (C.c_int, [C.c_uint]),
     "unet_profile_reset": (C.c_int, []),
     "unet_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),

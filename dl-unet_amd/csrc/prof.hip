@@ -16,6 +16,7 @@ namespace unet {
 struct ProfRec { hipEvent_t a, b; int kind; double flops, exec_flops, bytes; char row[40]; char tag[96]; };
 static std::mutex g_mu;
 static bool g_on = false;
+static unsigned g_kinds = 0xFFFFFFFFu;     // launch kinds (PK_*) that get events while profiling is on (unet_profile_select)
 static bool g_open = false;                 // the last prof_begin pushed a record that still waits for its end event
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -41,6 +42,7 @@ void prof_begin(int kind, const char *tag, hipStream_t st, double alg_flops, dou
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     g_open = false;
+    if (!((g_kinds >> kind) & 1u)) return;
     ProfRec r{get_event(), get_event(), kind, alg_flops, exec_flops, alg_bytes, {0}, {0}};
     if (!r.a || !r.b) {                      // no record: give back what was obtained, prof_end then does nothing
         if (r.a) g_pool.push_back(r.a);
@@ -73,6 +75,13 @@ int unet_profile_enable(int on)
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
     g_open = false;
+    return 0;
+}
+
+int unet_profile_select(unsigned kinds)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_kinds = kinds;
     return 0;
 }
 

@@ -142,14 +142,17 @@ int unet_dp_broadcast(unet_handle *h, void *buf, size_t count, int root, void *s
 int unet_dp_join(unet_handle *h, void *stream);
 
 /* ---- measurement -----------------------------------------------------------------------------
- * Optional HIP-event timing around every kernel launch, recorded on the launch stream (bench.py's roofline block and
- * per-layer table are measured with this inside its timed region).  Every launch records its kernel kind, the SURVEY 8a
+ * Optional HIP-event timing around kernel launches, recorded on the launch stream.  A pair of events per launch costs ~1 ms
+ * per training step when every launch carries one, so bench.py selects only the dominant kernel kind inside its timed region
+ * (unet_profile_select) and builds the per-layer table in a separate, fully instrumented pass.  Every launch records its kernel kind, the SURVEY 8a
  * row it belongs to, its algorithmic FLOPs (2*MAC, in-bounds taps only), the FLOPs the matrix cores execute for it
  * (Winograd: 16/36 of the direct count; tile padding included) and its algorithmic HBM bytes.
  * kind: 0 implicit GEMM (igemm*.hip), 1 weight gradient, 2 its split-K reduce, 3 Winograd 3x3 (wino.hip),
  *       4 conv11c stencil, 5 element-wise / reductions (pool, head, loss, SGD, packers), 6 RCCL collectives.
  * unet_profile_read synchronises on the recorded events and returns totals of one kind since the last reset.       */
 int unet_profile_enable(int on);
+/* launch kinds that get events while profiling is on: bit k = kind k (default: all) */
+int unet_profile_select(unsigned kinds);
 int unet_profile_reset(void);
 int unet_profile_read(int kind, double *ms_total, long *launches, double *flops_total, double *exec_flops_total,
                       double *bytes_total);
