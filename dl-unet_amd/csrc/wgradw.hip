@@ -298,15 +298,15 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
         }
     }
 
-    // ---- slab: [xi 16][ci 64][cj 64] | db[64].  D lane layout: ci = 4*kg + r, cj = l15.
+    // ---- slab: [xi 16][cj 64][ci 64] | db[64].  D lane layout: ci = 4*kg + r, cj = l15: ci is the fast index, so the four
+    // accumulator registers of a (xi, c) are one 16-byte store (32 store instructions per lane instead of 128 dword stores) and
+    // the reduce, with its threads along ci, writes the caller's OIHW gradient as consecutive 36-byte runs.
     float *slab = p.slab + (size_t)(tile * k.nsplit + part) * k.pstride;
 #pragma unroll
     for (int x = 0; x < 16; ++x)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                slab[(x * 64 + wi * 16 + 4 * kg + r) * 64 + (2 * wj + c) * 16 + l15] = acc[x][c][r];
+            *(f32x4 *)(slab + (x * 64 + (2 * wj + c) * 16 + l15) * 64 + wi * 16 + 4 * kg) = acc[x][c];
     if (wi == 0) {
         // bias partial: sum over this lane's tiles (.x + .y) and over the 4 k groups (lanes l15 + 16*kg)
 #pragma unroll
@@ -327,10 +327,10 @@ __global__ __launch_bounds__(64 * PG) void wgradw_reduce_kernel(const float *__r
                                                             float *__restrict__ out, long si, long sj, long st,
                                                             float *__restrict__ db, int db_c0)
 {
-    // block = one (tile, ci); 64 threads along cj x PG part groups
-    const int tile = blockIdx.x >> 6, i = blockIdx.x & 63;
-    const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const float *src = slab + (size_t)tile * nsplit * pstride + (size_t)i * 64 + j;
+    // block = one (tile, cj); 64 threads along ci (the slab's fast index) x PG part groups
+    const int tile = blockIdx.x >> 6, jb = blockIdx.x & 63;
+    const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;          // j: this thread's ci within the tile
+    const float *src = slab + (size_t)tile * nsplit * pstride + (size_t)jb * 64 + j;
     float m[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) m[x] = 0.f;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64 * PG) void wgradw_reduce_kernel(const float *__r
             r[2][c] = 0.5f * (m[4 + c] + m[8 + c]) + m[12 + c];
         }
         const int it = tile / ntile_j, jt = tile - it * ntile_j;
-        float *o = out + (size_t)(it * 64 + i) * si + (size_t)(jt * 64 + j) * sj;
+        float *o = out + (size_t)(it * 64 + j) * si + (size_t)(jt * 64 + jb) * sj;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             o[(a * 3 + 0) * st] = r[a][0] + 0.5f * (r[a][1] + r[a][2]);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * PG) void wgradw_reduce_kernel(const float *__r
             o[(a * 3 + 2) * st] = 0.5f * (r[a][1] + r[a][2]) + r[a][3];
         }
     }
-    if (db && i == 0 && (tile / ntile_j) == 0) {
+    if (db && jb == 0 && (tile / ntile_j) == 0) {
         // bias gradient of channel tile jt: slabs of the tiles (it = 0, jt)
         __syncthreads();
         const int jt = tile % ntile_j;
