@@ -74,17 +74,43 @@ class DataParallel:
             return
         import _hip
         L = _hip.lib()
-        # rendezvous: rank 0 makes the id, torch.distributed (any backend) carries the 128 bytes
+        # rendezvous: rank 0 makes the id, torch.distributed (any backend) carries the 128 bytes (+ one flag byte: a failure on
+        # rank 0 must reach the other ranks, or they would wait in the broadcast / inside ncclCommInitRank for ever)
         idbuf = (C.c_ubyte * 128)()
+        ok0, err0 = 1, ""
         if self.rank == 0:
-            _hip.check(L.unet_dp_unique_id(idbuf), "unet_dp_unique_id")
+            try:
+                _hip.check(L.unet_dp_unique_id(idbuf), "unet_dp_unique_id")
+            except RuntimeError as e:
+                ok0, err0 = 0, str(e)
+        on_gpu = self.world > 1 and dist.get_backend(group) == "nccl"
+        cdev = device if on_gpu else "cpu"
         if self.world > 1:
-            on_gpu = dist.get_backend(group) == "nccl"
-            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=device if on_gpu else "cpu")
+            t = torch.tensor(list(idbuf) + [ok0], dtype=torch.uint8, device=cdev)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            idbuf = (C.c_ubyte * 128)(*t.cpu().tolist())
+            vals = t.cpu().tolist()
+            idbuf = (C.c_ubyte * 128)(*vals[:128])
+            ok0 = vals[128]
+        if not ok0:
+            raise RuntimeError("data parallel: rank 0 could not create the RCCL rendezvous id %s" % err0)
+        err = ""
         with torch.cuda.device(device):
-            _hip.check(L.unet_dp_init(handle.h, self.rank, self.world, idbuf), "unet_dp_init")
+            try:
+                _hip.check(L.unet_dp_init(handle.h, self.rank, self.world, idbuf), "unet_dp_init")
+            except RuntimeError as e:
+                err = str(e)
+        if self.world > 1:
+            # every rank learns whether all of them have a communicator: a caller that falls back to another backend
+            # (bench.py) must do so on all ranks together
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if flag.item() == 0:
+                if not err:
+                    with torch.cuda.device(device):
+                        L.unet_dp_destroy(handle.h)
+                    err = "unet_dp_init failed on another rank"
+        if err:
+            raise RuntimeError(err)
         self._handle = handle
 
     def broadcast_parameters(self, params):
