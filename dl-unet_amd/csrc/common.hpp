@@ -155,8 +155,8 @@ size_t bias_grad_scratch_bytes(size_t M, int K);
 int conv1ch_fwd(const float *x, int B, int S, const float *w, const float *bias, int K, void *y, int es, hipStream_t st);
 int conv1ch_bwd(const float *x, int B, int S, int K, const void *dz, float *dw, float *db, float *scratch, int es, hipStream_t st);
 int head1x1_fwd(const void *x, int B, int H, int W, int C, const float *w, const float *bias, float *logits, int es, hipStream_t st);
-int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, void *dz, float *dw, float *db,
-                float *scratch, int es, hipStream_t st);
+int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, float dl_scale, void *dz, float *dw,
+                float *db, float *scratch, int es, hipStream_t st);   // every use of dlogits is dlogits * dl_scale (data parallel: 1/world)
 int maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, int es, hipStream_t st);
 int maxpool2_bwd(const void *pre, const void *dy, void *dpre, int B, int H, int W, int C, int es, hipStream_t st);
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T *__restrict__ 
 //           dw[k][c] = sum_m dl_k[m]*x[m][c];  db[k] = sum_m dl_k[m]   (partials per block)
 template <int C, typename T>
 __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const T *__restrict__ x, const float *__restrict__ w,
-                                                          const float *__restrict__ dlogits, T *__restrict__ dz,
+                                                          const float *__restrict__ dlogits, float dls, T *__restrict__ dz,
                                                           float *__restrict__ partial, int B, int HW)
 {
     constexpr int CG = C / 4, PPP = 256 / CG;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const T *__restrict__ 
     float sb0 = 0.f, sb1 = 0.f;
     for (size_t pix = (size_t)blockIdx.x * PPP + pl; pix < npix; pix += (size_t)gridDim.x * PPP) {
         const size_t img = pix / HW, rem = pix - img * HW;
-        const float d0 = dlogits[(img * 2) * HW + rem], d1 = dlogits[(img * 2 + 1) * HW + rem];
+        const float d0 = dlogits[(img * 2) * HW + rem] * dls, d1 = dlogits[(img * 2 + 1) * HW + rem] * dls;
         const float4_ v = load4(x + pix * C + cg * 4);
         float4_ g;
 #pragma unroll
@@ -671,7 +671,7 @@ int head1x1_fwd(const void *x, int B, int H, int W, int C, const float *w, const
 }
 
 static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 512); }
-int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, void *dz, float *dw, float *db,
+int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, float dl_scale, void *dz, float *dw, float *db,
                 float *scratch, int es, hipStream_t st)
 {
     ARG_CHECK(C == 64 || C == 32, "head1x1: C=%d unsupported (32 or 64)", C);
@@ -679,11 +679,11 @@ int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const
     const double npix = (double)B * H * W;
     prof_begin(PK_ELEMWISE, "head1x1_bwd", st, 8.0 * npix * C, 0.0, npix * (2.0 * es * C + 8));
     if (es == 2) {
-        if (C == 64) hipLaunchKernelGGL((head1x1_bwd_kernel<64, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)x, w, dlogits, (bf16_t *)dz, scratch, B, H * W);
-        else hipLaunchKernelGGL((head1x1_bwd_kernel<32, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)x, w, dlogits, (bf16_t *)dz, scratch, B, H * W);
+        if (C == 64) hipLaunchKernelGGL((head1x1_bwd_kernel<64, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)x, w, dlogits, dl_scale, (bf16_t *)dz, scratch, B, H * W);
+        else hipLaunchKernelGGL((head1x1_bwd_kernel<32, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)x, w, dlogits, dl_scale, (bf16_t *)dz, scratch, B, H * W);
     } else {
-        if (C == 64) hipLaunchKernelGGL((head1x1_bwd_kernel<64, float>), dim3(nb), dim3(256), 0, st, (const float *)x, w, dlogits, (float *)dz, scratch, B, H * W);
-        else hipLaunchKernelGGL((head1x1_bwd_kernel<32, float>), dim3(nb), dim3(256), 0, st, (const float *)x, w, dlogits, (float *)dz, scratch, B, H * W);
+        if (C == 64) hipLaunchKernelGGL((head1x1_bwd_kernel<64, float>), dim3(nb), dim3(256), 0, st, (const float *)x, w, dlogits, dl_scale, (float *)dz, scratch, B, H * W);
+        else hipLaunchKernelGGL((head1x1_bwd_kernel<32, float>), dim3(nb), dim3(256), 0, st, (const float *)x, w, dlogits, dl_scale, (float *)dz, scratch, B, H * W);
     }
     hipLaunchKernelGGL(head1x1_bwd_reduce_kernel, dim3(cdiv(2 * C + 2, 4)), dim3(256), 0, st, (const float *)scratch, nb, C, dw, db);
     prof_end(st);
@@ -740,7 +740,7 @@ size_t unet_head1x1_bwd_scratch_bytes(int B, int H, int W, int C) { return (size
 int unet_head1x1_bwd(const void *x, int B, int H, int W, int C, const void *w, const void *dlogits, void *dz,
                      void *dw, void *db, void *scratch, void *stream)
 {
-    return head1x1_bwd(x, B, H, W, C, (const float *)w, (const float *)dlogits, dz, (float *)dw, (float *)db, (float *)scratch, op_es(), (hipStream_t)stream);
+    return head1x1_bwd(x, B, H, W, C, (const float *)w, (const float *)dlogits, 1.0f, dz, (float *)dw, (float *)db, (float *)scratch, op_es(), (hipStream_t)stream);
 }
 int unet_maxpool2_fwd(const void *x, void *y, int B, int H, int W, int C, void *stream)
 {

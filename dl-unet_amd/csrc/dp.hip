@@ -84,6 +84,9 @@ struct unet_dp {
 int unet_dp_free(unet_dp *d)
 {
     if (!d) return 0;
+    // collectives of this communicator may still be queued (a second enable_data_parallel, or a second module on the
+    // handle's device, re-initialises the slot): drain its stream before the communicator goes away
+    if (d->cs) (void)hipStreamSynchronize(d->cs);
     if (d->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
     for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->done) (void)hipEventDestroy(d->done);
@@ -92,9 +95,17 @@ int unet_dp_free(unet_dp *d)
     return 0;
 }
 
-// handle layout is private to net.hip: these three accessors are all dp.hip needs
+// handle layout is private to net.hip: these two accessors are all dp.hip needs
 unet_dp **unet_handle_dp_slot(unet_handle *h);
 int unet_handle_device(const unet_handle *h);
+
+// stream calls run on the communicator's device: the events and the communicator stream belong to it
+#define DP_CHECK_DEVICE(d, what)                                                                                       \
+    do {                                                                                                               \
+        int cur_ = -1;                                                                                                 \
+        HIP_TRY(hipGetDevice(&cur_));                                                                                  \
+        ARG_CHECK(cur_ == (d)->device, what ": the communicator belongs to device %d but device %d is current", (d)->device, cur_); \
+    } while (0)
 
 extern "C" {
 
@@ -115,7 +126,7 @@ int unet_dp_init(unet_handle *h, int rank, int world, const void *id_bytes)
     ARG_CHECK(world >= 1 && rank >= 0 && rank < world, "unet_dp_init: bad rank %d of %d", rank, world);
     if (int rc = rccl_load()) return rc;
     unet_dp **slot = unet_handle_dp_slot(h);
-    if (*slot) { (void)unet_dp_free(*slot); *slot = nullptr; }
+    if (*slot) { (void)unet_dp_free(*slot); *slot = nullptr; }      // drains the old communicator's stream first
     int cur = -1;
     HIP_TRY(hipGetDevice(&cur));
     ARG_CHECK(cur == unet_handle_device(h), "unet_dp_init: the handle belongs to device %d but device %d is current", unet_handle_device(h), cur);
@@ -160,6 +171,7 @@ int unet_dp_allreduce(unet_handle *h, void *buf, size_t count, void *stream)
     ARG_CHECK(h && buf, "unet_dp_allreduce: null argument");
     unet_dp *d = *unet_handle_dp_slot(h);
     ARG_CHECK(d, "unet_dp_allreduce: unet_dp_init has not been called on this handle");
+    DP_CHECK_DEVICE(d, "unet_dp_allreduce");
     if (count == 0) return 0;
     hipEvent_t ev = d->ev[d->next++ % DP_EVENTS];
     HIP_TRY(hipEventRecord(ev, (hipStream_t)stream));           // the bucket is final on the caller's stream here
@@ -181,6 +193,7 @@ int unet_dp_broadcast(unet_handle *h, void *buf, size_t count, int root, void *s
     unet_dp *d = *unet_handle_dp_slot(h);
     ARG_CHECK(d, "unet_dp_broadcast: unet_dp_init has not been called on this handle");
     ARG_CHECK(root >= 0 && root < d->world, "unet_dp_broadcast: bad root %d", root);
+    DP_CHECK_DEVICE(d, "unet_dp_broadcast");
     if (count == 0) return 0;
     hipEvent_t ev = d->ev[d->next++ % DP_EVENTS];
     HIP_TRY(hipEventRecord(ev, (hipStream_t)stream));
@@ -194,8 +207,14 @@ int unet_dp_join(unet_handle *h, void *stream)
     ARG_CHECK(h, "unet_dp_join: null handle");
     unet_dp *d = *unet_handle_dp_slot(h);
     ARG_CHECK(d, "unet_dp_join: unet_dp_init has not been called on this handle");
+    DP_CHECK_DEVICE(d, "unet_dp_join");
     HIP_TRY(hipEventRecord(d->done, d->cs));
+    // under profiling the wait is bracketed on the CALLER's stream: its duration is the exposed (non-overlapped) part
+    // of the step's collectives
+    ProfScope ps("allreduce");
+    prof_begin(PK_COMM, "join (exposed wait of the compute stream)", (hipStream_t)stream, 0.0, 0.0, 0.0);
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, d->done, 0));
+    prof_end((hipStream_t)stream);
     return 0;
 }
 

@@ -73,6 +73,7 @@ struct unet_handle {
     int device;
     int math;             // arithmetic of this handle's forwards (unet_config::math); -1 = the process default at each forward
     unet_dp *dp = nullptr;
+    float grad_scale = 1.f;   // unet_set_grad_scale: the backward reads dlogits * grad_scale (data parallel: 1/world)
     // plans of the training forwards still awaiting their backward, keyed by workspace pointer
     std::mutex mu;
     std::vector<std::pair<void *, Plan>> live;
@@ -388,7 +389,7 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
 extern "C" {
 
 const char *unet_last_error(void) { return g_err; }
-int unet_abi_version(void) { return 2; }
+int unet_abi_version(void) { return 3; }
 
 int unet_set_math(int mode)
 {
@@ -439,6 +440,14 @@ int unet_destroy(unet_handle *h)
 {
     if (h && h->dp) (void)unet_dp_free(h->dp);
     delete h;
+    return 0;
+}
+
+int unet_set_grad_scale(unet_handle *h, float scale)
+{
+    ARG_CHECK(h, "unet_set_grad_scale: null handle");
+    ARG_CHECK(scale > 0.f && scale <= 1.f, "unet_set_grad_scale: scale must be in (0, 1] (1/world), got %g", (double)scale);
+    h->grad_scale = scale;
     return 0;
 }
 
@@ -706,7 +715,7 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             ARG_CHECK(dlogits, "unet_backward: null dlogits");
             // finalconv backward, fused with the ReLU backward of conv12e -> dz of conv12e
             RowScope rs(FINAL, "bwd");
-            if ((rc = head1x1_bwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), (const float *)dlogits, WS(pl.g_d2[0]),
+            if ((rc = head1x1_bwd(WS(pl.d2[0]), B, pl.So, pl.So, ch[0], PARAM(2 * FINAL), (const float *)dlogits, h->grad_scale, WS(pl.g_d2[0]),
                                   GRAD(2 * FINAL), GRAD(2 * FINAL + 1), WS(pl.small), t_es, st))) return rc;
         }
         // conv_l2e: input d1[l] (ReLU output of conv_l1e)

@@ -68,12 +68,16 @@ class DataParallel:
         self.world = dist.get_world_size(group) if inited else 1
         self.rank = dist.get_rank(group) if inited else 0
         self._works = []
-        if backend == "torch":
-            if not inited:
-                raise RuntimeError("backend 'torch' needs torch.distributed.init_process_group first")
-            return
         import _hip
         L = _hip.lib()
+        if backend == "torch" and not inited:
+            raise RuntimeError("backend 'torch' needs torch.distributed.init_process_group first")
+        # gradients are linear in dlogits: the handle's backward reads dlogits / world (inside the head's backward kernel), so
+        # the SUM all-reduce of the buckets is the gradient of the global-batch mean loss
+        _hip.check(L.unet_set_grad_scale(handle.h, 1.0 / self.world), "unet_set_grad_scale")
+        self._handle = handle
+        if backend == "torch":
+            return
         # rendezvous: rank 0 makes the id, torch.distributed (any backend) carries the 128 bytes (+ one flag byte: a failure on
         # rank 0 must reach the other ranks, or they would wait in the broadcast / inside ncclCommInitRank for ever)
         idbuf = (C.c_ubyte * 128)()

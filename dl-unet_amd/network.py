@@ -85,7 +85,7 @@ class _UnetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, *params):
         dev = x.device.index
-        h = _handle(dev, module.base_ch)
+        h = module._get_handle(dev)
         B, _, S, _ = x.shape
         So = S - 184
         with torch.cuda.device(x.device):               # the library checks that the handle's device is current
@@ -103,15 +103,13 @@ class _UnetFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         params = ctx.saved_tensors
         module = ctx.module
-        h = _handle(ctx.dev, module.base_ch)
+        h = module._get_handle(ctx.dev)
         L = _hip.lib()
         buckets = module._buckets
         dp = module._dp
         with torch.cuda.device(dlogits.device):
             flat, grads = buckets.allocate([p.shape for p in params], dlogits.device)
-            dlogits = dlogits.contiguous()
-            if dp is not None and dp.world > 1:
-                dlogits = dlogits * (1.0 / dp.world)           # grads are linear in dlogits: SUM-reduce == mean
+            dlogits = dlogits.contiguous()     # with data parallel the handle reads it as dlogits / world (unet_set_grad_scale)
             ptab, gtab = _hip.ptr_table(params), _hip.ptr_table(grads)
             st = _hip.stream(dlogits.device)
             for s in range(buckets.n_stages()):
@@ -151,6 +149,7 @@ class Unet(nn.Module):
             m.weight = nn.Parameter(torch.empty_like(m.weight).normal_(mean=0, std=_init_std(name, cin)))
         self._dp = None
         self._buckets = None
+        self._own_handle = None
 
     # -- data parallel: batch-sharded replicas, gradients averaged with RCCL over xGMI -------------
     def enable_data_parallel(self, process_group=None, backend="rccl"):
@@ -162,9 +161,20 @@ class Unet(nn.Module):
         if not all(p.is_cuda for p in params):
             raise RuntimeError("enable_data_parallel: move the module to its HIP device first (.to('cuda:N'))")
         dev = params[0].device
-        self._dp = dp_mod.DataParallel(_handle(dev.index, self.base_ch), dev, process_group, backend)
+        # a handle of this module's own: the communicator, its stream and the 1/world gradient scale live in the handle,
+        # and the per-device handle is shared by every other Unet on the device
+        self._own_handle = _hip.Handle(self.base_ch, dev.index)
+        self._dp = dp_mod.DataParallel(self._own_handle, dev, process_group, backend)
         self._dp.broadcast_parameters(params)
         return self
+
+    def _get_handle(self, device_index):
+        h = self._own_handle
+        if h is not None:
+            if h.device != device_index:
+                raise RuntimeError("this Unet was set up for data parallel on device %d; it cannot run on device %d" % (h.device, device_index))
+            return h
+        return _handle(device_index, self.base_ch)
 
     def _params(self):
         out = []
@@ -201,7 +211,7 @@ class Unet(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _UnetFunction.apply(t, self, *params)
         # inference (trainer.py:95 no_grad): no activation-gradient storage
-        h = _handle(t.device.index, self.base_ch)
+        h = self._get_handle(t.device.index)
         B, _, S, _ = t.shape
         with torch.cuda.device(t.device):
             nbytes = h.workspace_bytes(B, S, False)

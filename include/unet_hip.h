@@ -130,8 +130,11 @@ int unet_debug_buffer(const unet_handle *h, int B, int S, int training, const ch
  *                       each unet_backward_stage to overlap the bucket with the next stage)
  *   unet_dp_join      : `stream` waits for every collective issued so far (call before the optimizer step)
  *   unet_dp_broadcast : `count` fp32 from `root` to all ranks (initial parameters); same ordering as allreduce
- * Gradients are linear in dlogits: scale dlogits by 1/world (unet_bce_logits grad_scale) and SUM == global-batch mean. */
+ * Gradients are linear in dlogits, so SUM-reducing the gradients of dlogits / world gives the global-batch mean:
+ *   unet_set_grad_scale : the backward of this handle reads dlogits * scale (applied inside the head's backward kernel, no
+ *                         extra pass); 1.0 at creation.  A replica of a world-N job sets 1/N once. */
 #define UNET_DP_ID_BYTES 128
+int unet_set_grad_scale(unet_handle *h, float scale);
 int unet_dp_unique_id(void *id_out_host);
 int unet_dp_init(unet_handle *h, int rank, int world, const void *id_host);
 int unet_dp_destroy(unet_handle *h);

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libunet_hip.so does not export %s" % name
     assert sorted(_hip.EXPORTS) == declared          # the ctypes table covers the whole header
-    assert L.unet_abi_version() == 2
+    assert L.unet_abi_version() == 3
 
 
 def test_size_contract_no_gpu_needed():
@@ -158,3 +158,82 @@ def test_dp_bucket_allreduce_equals_global_batch_gradient_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert "WORST" in outs[0]
+
+
+def test_bench_line_is_short_and_keeps_the_contract_fields():
+    """The driver keeps an 8 KB tail of stdout: the result line must stay far below it whatever the tables hold.  Input:
+    round 2's committed full result (27 KB, 75 layer rows) through bench.split_line."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02_e_bench.json")))
+    full["cpu_baseline"].update({"gflops": 790.0, "iters": 5, "s_per_iter": 1.1,
+                                 "logits_parity": {"max_abs_err_over_max_abs_ref": 2.1e-6, "bound": 1e-3, "ok": True}})
+    full["comm"] = {"gradient_allreduce": "rccl", "ranks": 8, "rccl_version": 22204, "message_mb": 124.1, "buckets": 6}
+    line, detail = bench.split_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT <= 4096, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "comm", "detail"):
+        assert k in back, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "alg_bytes_per_launch"):
+        assert k in back["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample", "gflops", "logits_parity"):
+        assert k in back["cpu_baseline"], k
+    assert "workload" in back["config"] and "model" not in back["config"]
+    assert "layers" not in back and "kernels" not in back and "table" not in back["cpu_baseline"]
+    assert len(detail["layers"]) > 50                      # nothing is lost: the side file has the tables
+    # free text cannot push the numbers out: an absurdly long kernel name is cut
+    full["roofline"]["kernel"] = "k" * 5000
+    assert len(json.dumps(bench.split_line(full, "x.json")[0])) < bench.LINE_LIMIT
+
+
+def test_bench_gpus_n_starts_its_own_ranks_dry_launch():
+    """`python3 bench.py --gpus N` without WORLD_SIZE must launch N child ranks itself (the driver's plain command);
+    --dry-launch prints what it would start.  No torch import, no GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2", "--math", "2", "--dry-launch"],
+                         env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    spec = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert len(spec) == 4
+    ports = set()
+    for r, s in enumerate(spec):
+        assert s["argv"][0] == sys.executable and s["argv"][1].endswith("bench.py")
+        assert "--dry-launch" not in s["argv"] and s["argv"][2:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--math", "2"]
+        e = s["env"]
+        assert e["RANK"] == str(r) and e["LOCAL_RANK"] == str(r) and e["WORLD_SIZE"] == "4"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(e["MASTER_PORT"])
+    assert len(ports) == 1
+
+
+def test_bench_launcher_relays_rank0_line_and_exit_codes(tmp_path):
+    """The launcher itself (bench.launch) with stand-in children: rank 0's JSON line is relayed, a failing rank's exit code
+    comes back and the other ranks are stopped."""
+    import bench
+    script = os.path.join(tmp_path, "child.py")
+    with open(script, "w") as f:
+        f.write("import os, sys, time, json\n"
+                "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
+                "if mode == 'ok':\n"
+                "    print('chatter from rank %d' % r)\n"
+                "    if r == 0: print(json.dumps({'metric': 'm', 'value': 1.5, 'n_gpus': int(os.environ['WORLD_SIZE'])}))\n"
+                "elif mode == 'fail':\n"
+                "    if r == 1: sys.exit(7)\n"
+                "    time.sleep(60)\n")
+    runner = os.path.join(tmp_path, "run.py")
+    with open(runner, "w") as f:
+        f.write("import sys; sys.path.insert(0, %r)\nimport bench\n"
+                "bench.child_specs = lambda args, argv, port=None: [([sys.executable, %r, argv[0]], {'RANK': str(r), 'WORLD_SIZE': str(args.gpus)}) for r in range(args.gpus)]\n"
+                "args = bench.parse_args(['--gpus', '3'])\n"
+                "sys.exit(bench.launch(args, [sys.argv[1]]))\n" % (ROOT, script))
+    ok = subprocess.run([sys.executable, runner, "ok"], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0, ok.stderr
+    import json
+    assert json.loads(ok.stdout.strip()) == {"metric": "m", "value": 1.5, "n_gpus": 3}       # exactly one line on stdout
+    assert "chatter from rank 1" in ok.stderr
+    t0 = __import__("time").time()
+    bad = subprocess.run([sys.executable, runner, "fail"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 7 and bad.stdout.strip() == "" and __import__("time").time() - t0 < 30

@@ -472,8 +472,9 @@ def test_rccl_communicator_behind_the_c_abi_single_rank(net):
     plain = [p.grad.clone() for p in m.parameters()]
     before = [p.detach().clone() for p in m.parameters()]
     m.enable_data_parallel(backend="rccl")              # no torch.distributed: a communicator of one rank
-    h = network._handle(0, m.base_ch)
-    assert L.unet_dp_world(h.h) == 1
+    h = m._get_handle(0)                                # the module's own handle: communicator + gradient scale live there
+    assert h is not network._handle(0, m.base_ch)
+    assert L.unet_dp_world(h.h) == 1 and L.unet_dp_world(network._handle(0, m.base_ch).h) == 0
     assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))        # broadcast from rank 0 == identity
     m.zero_grad(set_to_none=True)
     m(x).backward(dl)
