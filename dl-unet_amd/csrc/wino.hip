@@ -49,6 +49,7 @@ struct WinoP {
     int nsteps;              // total channels / 8
     FastDiv d_tpi, d_tx;
     int xbytes[2], ubytes;   // buffer-descriptor sizes (bytes) of the sources and of U; 0 if any exceeds 2 GiB
+    int gn, gn_shift;        // tile order: n-tiles are walked in groups of gn (a power of two dividing ntiles), n fastest inside a group
 };
 
 
@@ -154,10 +155,43 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int nt = slot / p.mtiles, mt = slot - nt * p.mtiles;
+    // consecutive slots (= workgroups resident together on an XCD, sharing its L2): gn n-tiles of one m-tile, then the next
+    // m-tile; after all m-tiles the next group of n-tiles.  gn = 1 is n-major (the U block shared, every patch image distinct)
+    int nt, mt;
+    {
+        const int per = p.mtiles << k.gn_shift;
+        const int ng = slot / per, rem = slot - ng * per;
+        mt = rem >> k.gn_shift;
+        nt = (ng << k.gn_shift) + (rem & (k.gn - 1));
+    }
     const int T0 = mt * 64, n0 = nt * 32;
     const int R0 = fdiv(T0, k.d_tx);
 
+    // U: the 32 channels are half (nt & 1) of the 64-channel block nt >> 1
+    const float *ublk = k.U + (size_t)(nt >> 1) * ns * 8192 + (nt & 1) * 4096 + (4 * wave) * 256 + lane * 4;
+    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane byte offset is fixed for the
+    // whole tile, the channel step goes into the scalar offset, and pixels outside the tensor are offsets beyond
+    // num_records (the range check returns zeros) - no per-step address VALU at all.  Needs tensors < 2 GiB.
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, BUF ? k.xbytes[0] : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)k.U, 0, BUF ? k.ubytes : 0, 0x00020000);
+    const int u_voff = ((4 * wave) * 256 + lane * 4) * 4;
+    const int u_soff0 = ((nt >> 1) * ns * 8192 + (nt & 1) * 4096) * 4;
+    int uissued = 0;
+    auto issue_u = [&]() {
+        const int buf = uissued & 1;
+        unsigned char *ub = smem + W32_UBASE + buf * 16384 + (4 * wave) * 1024;
+        if (BUF) {
+            const int us = u_soff0 + uissued * 32768;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(ub + i * 1024), 16, u_voff, us + i * 1024, 0, 0);
+        } else {
+            const float *us = ublk + (size_t)uissued * 8192;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
+        }
+        ++uissued;
+    };
     // ---- DMA role: patch instructions i = wave + 4*ii (i < 18): 5 for waves 0,1, 4 for waves 2,3; U pieces 4*wave .. +3
     constexpr int NPI = 5;
     const int npi = wave < 2 ? 5 : 4;
@@ -200,20 +234,10 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     }
     const float *sp = p.src[0].p;
     int snch = p.src[0].nch, kc = 0, pissued = 0;
-    // U: the 32 channels are half (nt & 1) of the 64-channel block nt >> 1
-    const float *ublk = k.U + (size_t)(nt >> 1) * ns * 8192 + (nt & 1) * 4096 + (4 * wave) * 256 + lane * 4;
-    // BUF: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane byte offset is fixed for the
-    // whole tile, the channel step goes into the scalar offset, and pixels outside the tensor are offsets beyond
-    // num_records (the range check returns zeros) - no per-step address VALU at all.  Needs tensors < 2 GiB.
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, BUF ? k.xbytes[0] : 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)k.U, 0, BUF ? k.ubytes : 0, 0x00020000);
-    const int u_voff = ((4 * wave) * 256 + lane * 4) * 4;
-    const int u_soff0 = ((nt >> 1) * ns * 8192 + (nt & 1) * 4096) * 4;
     if (BUF) {
 #pragma unroll
         for (int ii = 0; ii < NPI; ++ii) poff[ii] = poff[ii] >= 0 ? poff[ii] * 4 : (int)0x80000000;
     }
-
     const int tl = wave * 16 + l15;
     const int offA = tl * 32 + (((kg >> 1) ^ ((tl >> 3) & 1)) * 16) + (kg & 1) * 8;
     int offB;
@@ -229,20 +253,15 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     const int b_rd = W32_UBASE + lane * 16;
 
     // one stage = this wave's patch instructions + its 4 U pieces (9 or 8 LDS-DMA instructions)
-    auto issue_stage = [&]() {
+    auto issue_patch = [&]() {
         const int buf = pissued & 1;
         unsigned char *sb = smem + buf * WINO_PATCH + wave * 1024;
-        unsigned char *ub = smem + W32_UBASE + buf * 16384 + (4 * wave) * 1024;
         if (BUF) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + ii * 4096), 16, poff[ii], kc * 4, 0, 0);
             if (wave < 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(sb + 16384), 16, poff[4], kc * 4, 0, 0);
-            const int us = u_soff0 + pissued * 32768;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(ub + i * 1024), 16, u_voff, us + i * 1024, 0, 0);
         } else {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
@@ -253,9 +272,6 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
                 const float *g = poff[4] >= 0 ? sp + (poff[4] + kc) : p.zeros;
                 GLDS16(g, sb + 16384);
             }
-            const float *us = ublk + (size_t)pissued * 8192;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) GLDS16(us + i * 256, ub + i * 1024);
         }
         ++pissued;
         kc += 8;
@@ -267,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
             for (int ii = 0; ii < NPI; ++ii) { const int o = poff1[ii * 256]; poff[ii] = BUF ? (o >= 0 ? o * 4 : (int)0x80000000) : o; }
         }
     };
+    auto issue_stage = [&]() { issue_patch(); issue_u(); };
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -514,6 +531,11 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
             }
         }
     }
+    // tile order: all n-tiles of an m-tile are neighbours (the workgroups resident together re-read one patch image from L2
+    // instead of 64 different ones from HBM): 0.6-1 % per step against n-major order (UNET_WINO_GN=1), measured round 3
+    static const int gn_env = [] { const char *e = getenv("UNET_WINO_GN"); return e ? atoi(e) : 64; }();
+    q.gn = 1; q.gn_shift = 0;
+    while (q.gn * 2 <= gn_env && q.p.ntiles % (q.gn * 2) == 0) { q.gn *= 2; ++q.gn_shift; }
     static bool attr32[64] = {false}, attr32b[64] = {false};
     auto k32 = buf ? wino32_f32_kernel<true> : wino32_f32_kernel<false>;
     if (int rc_ = ensure_dynamic_lds((const void *)k32, W32_TOTAL, buf ? attr32b : attr32)) return rc_;
