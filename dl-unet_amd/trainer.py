@@ -79,14 +79,20 @@ def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_di
         first_epoch = int(extra.get("epoch", -1)) + 1
         my_patience = int(extra.get("my_patience", 0))
         resumed_best = extra.get("loss_best_epoch")
+        if extra.get("goal_armed") is False:                   # the goal had been reached (and cleared) before the interruption
+            when_to_stop = None
     else:
         resumed_best = None
+        extra = {}
 
     maybe_mkdir_p(os.path.join(fold_dir, 'progress'))
     maybe_mkdir_p(os.path.join(fold_dir, 'models'))
 
     loss_best_epoch = 100000.0 if resumed_best is None else float(resumed_best)
     progress = {k: None for k in ('train_iou', 'train_pe', 'val_iou', 'val_pe', 'loss', 'loss_val')}
+    for k, v in (extra.get("progress") or {}).items():         # a resumed run goes on writing the interrupted run's series
+        if k in progress and len(v):
+            progress[k] = np.array(v, dtype=np.float64)
 
     epoch = first_epoch - 1
     for epoch in range(first_epoch, epochs + 1):
@@ -161,8 +167,14 @@ def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_di
 
         if save_optimizer:
             import checkpoint
+            # state as it is at the END of this epoch: the patience reset and the goal test below are anticipated
+            armed_after = when_to_stop is not None and not (val_eval_epoch[0] > goal)
+            patience_after = my_patience
+            if when_to_stop is None and my_patience == scheduler.patience:
+                patience_after = -1
             checkpoint.save_checkpoint(os.path.join(fold_dir, 'models', 'checkpoint_latest.pth'), unet, optimizer, scheduler,
-                                       epoch=epoch, my_patience=my_patience, loss_best_epoch=float(loss_best_epoch))
+                                       epoch=epoch, my_patience=patience_after, loss_best_epoch=float(loss_best_epoch),
+                                       goal_armed=armed_after, progress={k: [float(x) for x in v] for k, v in progress.items()})
 
         if when_to_stop is not None:
             # goal armed (trainer.py:185-214): the periodic checkpoint and the LR-floor stop are skipped this epoch

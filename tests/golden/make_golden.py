@@ -57,6 +57,37 @@ def run_net(network, params_np, x_np, dl_np, dtype):
     return out
 
 
+def main_s572_grad():
+    """G3b: the BASELINE tile size itself, B=1: logits and all 46 gradients of the reference in fp32 and fp64 as per-tensor
+    checksums + 64 strided samples (unet_S572_grad.npz; ~10 min, the fp64 backward dominates).
+    Run:  python tests/golden/make_golden.py s572grad"""
+    network, _ = import_reference()
+    torch.set_num_threads(8)
+    S, B = 572, 1
+    params = prng.make_params(seed=0)
+    names = list(params.keys())
+    x = prng.make_input(1, B, S)
+    dl = prng.make_cotangent(2, (B, 2, S - 184, S - 184))
+    fx = {"meta": np.array(repr(dict(torch=torch.__version__, threads=torch.get_num_threads(), seed_w=0, S=S, B=B, seed_x=1, seed_dl=2)))}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        r = run_net(network, params, x, dl, dt)
+        fx["logits_sample_" + tag] = r["logits"][:, :, ::6, ::6].copy()
+        sums, samp_idx, samp = [], [], []
+        for k in names:
+            s, i, v = checksum(r["grad." + k], nsamp=64)
+            sums.append(s); samp_idx.append(i); samp.append(v)
+        fx["grad_sums_" + tag] = np.stack(sums)
+        fx["grad_samp_" + tag] = np.stack(samp)
+        fx["grad_samp_idx"] = np.stack(samp_idx)
+        for k in ("conv11c.weight", "conv11c.bias", "finalconv.weight", "finalconv.bias", "conv52c.bias", "upconv4.bias"):
+            fx["grad_full_%s_%s" % (k, tag)] = r["grad." + k]
+        print("S=572 %s done" % tag, flush=True)
+    fx["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "unet_S572_grad.npz"), **fx)
+    e = np.abs(fx["grad_samp_f32"] - fx["grad_samp_f64"]).max(axis=1) / fx["grad_sums_f64"][:, 2]
+    print("S=572 gradients done: reference's own fp32-vs-fp64 distance per tensor: worst %.3g (%s)" % (e.max(), names[int(e.argmax())]))
+
+
 def main():
     network, functions = import_reference()
     torch.set_num_threads(8)
@@ -170,4 +201,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "s572grad":
+        main_s572_grad()
+    else:
+        main()

@@ -74,6 +74,50 @@ def run_case(network, trainer, dataset):
             "n_model_saved_lines": sum(ln == "Model has been saved:" for ln in lines)}
 
 
+def run_series(network, trainer, S_, threads, dtype=torch.float32):
+    """One run of the reference's training() (2 epochs of 2 train batches + 1 validation batch of 2) at tile size S_ on
+    `threads` CPU threads: the six progress series."""
+    torch.manual_seed(0)
+    torch.set_num_threads(threads)
+    net = network.Unet().to(dtype)
+    net.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in prng.make_params(0).items()})
+
+    def mk(seed, n):
+        return [(torch.from_numpy(prng.make_input(seed + i, 2, S_)).to(dtype), torch.from_numpy(prng.make_labels(seed + i, 2, S_ - 184))) for i in range(n)]
+    out = io.StringIO()
+    with tempfile.TemporaryDirectory() as d:
+        with contextlib.redirect_stdout(out):
+            trainer.training(net, mk(10, 2), mk(20, 1), 1, 2, torch.device("cpu"), d, "".join(["ISBI", "2012"]))
+        return {f[:-4]: np.atleast_1d(np.loadtxt(os.path.join(d, "progress", f))).tolist()
+                for f in sorted(os.listdir(os.path.join(d, "progress")))}
+
+
+def main_series():
+    """tests/golden/trainer_series.json: the six progress series of the reference's training() at S=188 (4x4 masks) and S=220
+    (36x36 masks), each run in fp32 on 1, 2, 4 and 8 CPU threads and once in fp64 (model and images converted; the loop is
+    the reference's own).  Per series: `f32` (8 threads), `f64`, and `thread_spread` = max - min over the thread counts.
+    What they show: oneDNN's result hardly depends on the thread count (spread <= 5e-5 relative), so that is no
+    measure of what fp32 evaluation order does to the trajectory; the distance |f32 - f64| is: 1.4 % on the validation loss
+    after 4 SGD steps at S=188 (one pixel of the 4x4 mask flips with it) and 5e-6 at S=220.  A HIP run is therefore held to
+    the fp64 series within twice the reference's own fp32 distance from it (tests/test_net_gpu.py).
+    Run:  python tests/golden/make_golden_trainer.py series"""
+    network, trainer = import_reference()
+    out = {}
+    for S_ in (188, 220):
+        runs = {t: run_series(network, trainer, S_, t) for t in (1, 2, 4, 8)}
+        r64 = run_series(network, trainer, S_, 8, torch.float64)
+        series = {}
+        for name in runs[8]:
+            vals = np.array([runs[t][name] for t in (1, 2, 4, 8)])
+            series[name] = {"f32": runs[8][name], "f64": r64[name], "thread_spread": (vals.max(axis=0) - vals.min(axis=0)).tolist()}
+            print(S_, name, "f32", runs[8][name], "f64", r64[name], "thread spread", series[name]["thread_spread"])
+        out["S%d" % S_] = series
+    meta = {"torch": torch.__version__, "threads": [1, 2, 4, 8], "sizes": [188, 220], "epochs_arg": 1, "batch": 2,
+            "train_seeds": [10, 11], "val_seeds": [20], "weights_seed": 0, "dataset_arg": "run-time string 'ISBI2012' (no stop goal)"}
+    with open(os.path.join(HERE, "trainer_series.json"), "w") as f:
+        json.dump({"meta": meta, "sizes": out}, f, indent=1)
+
+
 def main():
     network, trainer = import_reference()
     runtime_name = "".join(["ISBI", "2012"])            # equal text, different object (what argv gives)
@@ -92,4 +136,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "series":
+        main_series()
+    else:
+        main()

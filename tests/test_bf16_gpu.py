@@ -201,3 +201,25 @@ def test_pool_head_conv1ch_bf16(hip):
     sc = scratch(hip.lib().unet_conv1ch_bwd_scratch_bytes(B, S, K))
     hip.check(hip.lib().unet_conv1ch_bwd(hip.ptr(keep(xi.float().cuda())), B, S, K, hip.ptr(keep(nhwc16(dzi))), hip.ptr(dwi), hip.ptr(dbi), hip.ptr(sc), hip.stream()))
     assert nerr(dwi, wi.grad) < TOL_F32 and nerr(dbi, dzi.sum((0, 2, 3))) < TOL_F32
+
+
+def test_bf16_weight_gradient_refuses_tensors_of_2GiB_loudly(hip):
+    """wgrad_bf16_kernel addresses its operands through 32-bit buffer descriptors: a tensor of 2 GiB or more (bf16 training at
+    config-#5-like sizes) must be REFUSED with an error, never computed wrongly or silently skipped.  X = 8 x 1024 x 1024 x
+    128 bf16 is exactly 2 GiB; nothing is launched, the gradient buffers keep their sentinel."""
+    B, H, C, K = 8, 1024, 128, 64
+    L = hip.lib()
+    x = torch.zeros(B, H, H, C, device="cuda", dtype=torch.bfloat16)
+    assert x.numel() * 2 == 2 ** 31
+    dz = torch.zeros(B, H - 2, H - 2, K, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(K, C, 3, 3, device="cuda")
+    dw = torch.full((K, C, 3, 3), 7.0, device="cuda"); db = torch.full((K,), 7.0, device="cuda")
+    sc = scratch(L.unet_conv3x3_bwd_scratch_bytes(B, H, H, C, K))
+    rc = L.unet_conv3x3_bwd(hip.ptr(x), H, H, C, 0, None, 0, B, H, H, hip.ptr(w), K, hip.ptr(dz), None, None, None, None, None,
+                            hip.ptr(dw), hip.ptr(db), hip.ptr(sc), hip.stream())
+    torch.cuda.synchronize()
+    assert rc != 0
+    assert b"2 GiB" in L.unet_last_error()
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        hip.check(rc, "conv3x3_bwd")
+    assert bool((dw == 7.0).all()) and bool((db == 7.0).all())

@@ -135,3 +135,17 @@ def test_sgd_oracle_matches_torch():
         tp.grad = torch.from_numpy(gg.copy()); opt.step()
         oracle_c.sgd_momentum(q, gg, buf, 1e-4, 0.99, i == 0)
     assert np.allclose(q, tp.detach().numpy(), rtol=0, atol=1e-7)
+
+
+def test_torch_restatement_f64_matches_reference_at_the_baseline_tile(golden_dir):
+    """S=572, B=1 (BASELINE tile): the torch restatement in fp64 reproduces the reference's fp64 logits samples and all 46
+    gradients (checksums + 64 samples per tensor, tests/golden/unet_S572_grad.npz) — the fixture the GPU accounting test at
+    572 stands on."""
+    g = np.load(os.path.join(golden_dir, "unet_S572_grad.npz"))
+    S, B = 572, 1
+    torch.set_num_threads(8)
+    p = torch_ref.params_to_torch(prng.make_params(0), torch.float64, requires_grad=True)
+    y = torch_ref.unet_forward(p, torch.from_numpy(prng.make_input(1, B, S)).double())
+    y.backward(torch.from_numpy(prng.make_cotangent(2, (B, 2, S - 184, S - 184))).double())
+    assert nerr(y.detach().numpy()[:, :, ::6, ::6], g["logits_sample_f64"]) < 1e-12
+    _checks({k: v.grad.numpy() for k, v in p.items()}, g, "f64", 1e-10)
