@@ -3,8 +3,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic tiles (BASELINE configs[1]:
 batch 8 per GPU, 572x572x1, fp32, 64-base-channel U-Net):
-    zero_grad -> Unet.forward -> BCE-with-logits (unweighted) -> backward
-    [-> RCCL gradient all-reduce, one bucket per backward stage, libunet_hip unet_dp_*] -> SGD(momentum) -> argmax
+    zero_grad -> Unet.forward -> BCE-with-logits (unweighted) + argmax masks (one kernel) -> backward
+    [-> RCCL gradient all-reduce, one bucket per backward stage, libunet_hip unet_dp_*] -> SGD(momentum)
 Inputs are resident in HBM before the timed region.  One process per GPU.
 
 `python3 bench.py --gpus N` starts its own ranks: when WORLD_SIZE is not in the environment and N > 1, this process —
@@ -394,15 +394,14 @@ def run_rank(args):
     g = torch.Generator(device="cpu").manual_seed(1 + rank)          # each rank its own shard of the global batch
     x = torch.rand(B, 1, S, S, generator=g).to(dev)
     labels = (torch.rand(B, 1, S - 184, S - 184, generator=g) >= 0.5).long().to(dev)
-    target = hip_optim.onehot2(labels, torch.empty(B, 2, S - 184, S - 184, device=dev))
 
     def step():
         opt.zero_grad(set_to_none=True)
         logits = net(x)
-        loss = hip_optim.bce_with_logits(logits, target)
+        loss, masks = hip_optim.bce_argmax_step(logits, labels)      # L1 + L2 in one pass: loss, its gradient, argmax masks
         loss.backward()
         opt.step()
-        return hip_optim.argmax2(logits.detach()), loss
+        return masks, loss
 
     def barrier():
         if use_dist:

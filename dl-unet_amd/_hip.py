@@ -53,6 +53,9 @@ _SIGS = {
     "unet_bce_scratch_bytes": (C.c_size_t, [C.c_size_t]),
     "unet_bce_logits": (C.c_int, [vp, vp, vp, C.c_long, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
                                   vp, vp, C.c_float, vp, vp]),
+    "unet_bce_step_scratch_bytes": (C.c_size_t, [C.c_size_t]),
+    "unet_bce_step": (C.c_int, [vp, C.c_long, C.c_long, C.c_long, vp, vp, C.c_long, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
+                                vp, vp, C.c_float, vp, vp, vp]),
     "unet_onehot2": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "unet_argmax2": (C.c_int, [vp, C.c_long, C.c_long, C.c_long, vp, C.c_int, C.c_int, C.c_int, vp]),
     "unet_sgd_momentum": (C.c_int, [vp, vp, vp, C.POINTER(C.c_size_t), C.c_int, C.c_float, C.c_float, C.c_int, vp]),

@@ -222,23 +222,40 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const T *__restrict__ 
     const size_t npix = (size_t)B * HW;
     float4_ a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     float sb0 = 0.f, sb1 = 0.f;
-    for (size_t pix = (size_t)blockIdx.x * PPP + pl; pix < npix; pix += (size_t)gridDim.x * PPP) {
+    // two pixels per trip: both loads are in flight before either is used (the loop is a dependent chain otherwise)
+    const size_t step = (size_t)gridDim.x * PPP;
+    for (size_t pix = (size_t)blockIdx.x * PPP + pl; pix < npix; pix += 2 * step) {
+        const size_t pixb = pix + step;
+        const bool okb = pixb < npix;
+        const size_t pb = okb ? pixb : pix;
         const size_t img = pix / HW, rem = pix - img * HW;
-        const float d0 = dlogits[(img * 2) * HW + rem] * dls, d1 = dlogits[(img * 2 + 1) * HW + rem] * dls;
+        const size_t imgb = pb / HW, remb = pb - imgb * HW;
         const float4_ v = load4(x + pix * C + cg * 4);
-        float4_ g;
+        const float4_ vb = load4(x + pb * C + cg * 4);
+        const float d0 = dlogits[(img * 2) * HW + rem] * dls, d1 = dlogits[(img * 2 + 1) * HW + rem] * dls;
+        float d0b = dlogits[(imgb * 2) * HW + remb] * dls, d1b = dlogits[(imgb * 2 + 1) * HW + remb] * dls;
+        if (!okb) { d0b = 0.f; d1b = 0.f; }
+        float4_ g, gb;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             g[c] = v[c] > 0.f ? d0 * w0[c] + d1 * w1[c] : 0.f;
             a0[c] = fmaf(d0, v[c], a0[c]);
             a1[c] = fmaf(d1, v[c], a1[c]);
         }
-        store4(dz + pix * C + cg * 4, g);
-        sb0 += d0; sb1 += d1;
-    }
-    __shared__ float red[PPP][2 * C + 2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { red[pl][cg * 4 + c] = a0[c]; red[pl][C + cg * 4 + c] = a1[c]; }
+        for (int c = 0; c < 4; ++c) {
+            gb[c] = vb[c] > 0.f ? d0b * w0[c] + d1b * w1[c] : 0.f;
+            a0[c] = fmaf(d0b, vb[c], a0[c]);
+            a1[c] = fmaf(d1b, vb[c], a1[c]);
+        }
+        store4(dz + pix * C + cg * 4, g);
+        if (okb) store4(dz + pixb * C + cg * 4, gb);
+        sb0 += d0 + d0b; sb1 += d1 + d1b;
+    }
+    // row pitch 2C+4 floats: 16-byte aligned rows, one ds_write_b128 per class instead of four conflicting dword writes
+    __shared__ __attribute__((aligned(16))) float red[PPP][2 * C + 4];
+    *(float4_ *)&red[pl][cg * 4] = a0;
+    *(float4_ *)&red[pl][C + cg * 4] = a1;
     if (cg == 0) { red[pl][2 * C] = sb0; red[pl][2 * C + 1] = sb1; }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * C + 2; e += 256) {
@@ -524,6 +541,54 @@ __global__ __launch_bounds__(256) void bce_final_kernel(const double *__restrict
     if (threadIdx.x == 0) *loss = (float)(red[0] / (double)n);
 }
 
+// L1 + L2 in one pass over the logits (trainer.py:60-82): the one-hot target [1-y, y] is never materialised, the loss
+// gradient and the argmax mask come out of the same read.  A thread owns a pixel (both class planes): 2 x 4 B logits + 8 B
+// label in, 2 x 4 B dlogits + 8 B mask out.  Logits / weight are addressed through strides (the trainer's centre crop of
+// preds is a view); dlogits and the mask are dense.  Loss partials per block in double, fixed-order finish in bce_final_kernel.
+constexpr int BCE_PX_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void bce_step_kernel(const float *__restrict__ x, long xsB, long xsC, long xsH,
+                                                       const long long *__restrict__ labels,
+                                                       const float *__restrict__ w, long wsB, long wsC, long wsH, long wsW,
+                                                       int H, int W, size_t npix, float *__restrict__ dx, float gscale,
+                                                       long long *__restrict__ mask, double *__restrict__ partial)
+{
+    const size_t b0 = (size_t)blockIdx.x * BCE_PX_PER_BLOCK;
+    double acc = 0.0;
+    const float inv_n = (float)(1.0 / (double)(2 * npix));
+    const size_t HW = (size_t)H * W;
+    for (int i = threadIdx.x; i < BCE_PX_PER_BLOCK; i += 256) {
+        const size_t e = b0 + i;
+        if (e >= npix) break;
+        const size_t bb = e / HW, rem = e - bb * HW;
+        const int yy = (int)(rem / W), xx = (int)(rem - (size_t)yy * W);
+        const float *px = x + bb * xsB + (long)yy * xsH + xx;
+        const float x0 = px[0], x1 = px[xsC];
+        const float y = (float)labels[e];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float xv = c ? x1 : x0, zv = c ? y : 1.f - y;
+            const float wv = w ? w[bb * wsB + c * wsC + yy * wsH + xx * wsW] : 1.f;
+            const float ax = fabsf(xv);
+            const float ex = expf(-ax);
+            const float l = fmaxf(xv, 0.f) - xv * zv + log1pf(ex);
+            acc += (double)(wv * l);
+            if (dx) {
+                const float sg = xv >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
+                dx[(bb * 2 + c) * HW + rem] = wv * (sg - zv) * inv_n * gscale;
+            }
+        }
+        if (mask) mask[e] = x1 > x0 ? 1 : 0;              // first maximum wins on ties -> class 0
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 __global__ void onehot2_kernel(const long long *__restrict__ labels, float *__restrict__ t, int B, size_t HW)
 {
     const size_t total = (size_t)B * HW;
@@ -670,7 +735,7 @@ int head1x1_fwd(const void *x, int B, int H, int W, int C, const float *w, const
     return 0;
 }
 
-static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 512); }
+static int head_bwd_blocks(int B, int H, int W) { return grid_for((size_t)B * H * W, 16 * 32, 2048); }
 int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, float dl_scale, void *dz, float *dw, float *db,
                 float *scratch, int es, hipStream_t st)
 {
@@ -768,6 +833,26 @@ int unet_bce_logits(const void *logits, const void *target, const void *weight, 
     HIP_TRY(hipGetLastError());
     return 0;
 }
+size_t unet_bce_step_scratch_bytes(size_t npix) { return ((npix + BCE_PX_PER_BLOCK - 1) / BCE_PX_PER_BLOCK) * sizeof(double); }
+int unet_bce_step(const void *logits, long xsB, long xsC, long xsH, const void *labels_i64, const void *weight, long wsB, long wsC,
+                  long wsH, long wsW, int B, int H, int W, void *loss_out, void *dlogits, float grad_scale, void *mask_i64, void *scratch,
+                  void *stream)
+{
+    const size_t npix = (size_t)B * H * W;
+    ARG_CHECK(npix > 0 && logits && labels_i64 && loss_out && scratch, "bce_step: bad arguments");
+    const int nb = (int)((npix + BCE_PX_PER_BLOCK - 1) / BCE_PX_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("L1.bce+L2.argmax");
+    // logits 8 B + label 8 B in, dlogits 8 B + mask 8 B out per pixel
+    prof_begin(PK_ELEMWISE, "bce_step", st, 24.0 * npix, 0.0, (double)npix * (16.0 + (dlogits ? 8.0 : 0.0) + (mask_i64 ? 8.0 : 0.0) + (weight ? 8.0 : 0.0)));
+    hipLaunchKernelGGL(bce_step_kernel, dim3(nb), dim3(256), 0, st, (const float *)logits, xsB, xsC, xsH, (const long long *)labels_i64,
+                       (const float *)weight, wsB, wsC, wsH, wsW, H, W, npix, (float *)dlogits, grad_scale, (long long *)mask_i64, (double *)scratch);
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, (const double *)scratch, nb, 2 * npix, (float *)loss_out);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int unet_onehot2(const void *labels_i64, void *target, int B, int H, int W, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;

@@ -33,24 +33,76 @@ class _BCEFn(torch.autograd.Function):
         return dl * g, None, None, None, None
 
 
+def _weight_strides(weight, logits):
+    """torch broadcasting of `weight` against [B,2,H,W] as four element strides (0 on broadcast axes); like the reference
+    (trainer.py:72-75), a [B,H,W] map is right-aligned: its first axis meets the CLASS axis (quirk Q4), other sizes raise."""
+    weight = weight.to(logits.device, torch.float32).contiguous()
+    shape = (1,) * (4 - weight.dim()) + tuple(weight.shape)
+    st = (0,) * (4 - weight.dim()) + tuple(weight.stride())
+    wstrides = []
+    for d in range(4):
+        if shape[d] == logits.shape[d]:
+            wstrides.append(st[d])
+        elif shape[d] == 1:
+            wstrides.append(0)
+        else:
+            raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
+                               "dimension %d" % (logits.shape[d], shape[d], d))
+    return weight, wstrides
+
+
+class _BCEStepFn(torch.autograd.Function):
+    """unet_bce_step: loss (+ its gradient) and the argmax mask from logits and integer labels in one device pass."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight, wstrides, grad_scale, want_mask):
+        B, two, H, W = logits.shape
+        assert two == 2
+        if logits.stride(3) != 1:
+            logits = logits.contiguous()
+        labels = labels.to(logits.device).reshape(B, H, W).contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        need_grad = logits.requires_grad
+        dl = torch.empty(B, 2, H, W, dtype=torch.float32, device=logits.device) if need_grad else None
+        mask = torch.empty(B, H, W, dtype=torch.int64, device=logits.device) if want_mask else None
+        sc = torch.empty(_hip.lib().unet_bce_step_scratch_bytes(B * H * W), dtype=torch.uint8, device=logits.device)
+        ws = wstrides if weight is not None else (0, 0, 0, 0)
+        _hip.run("unet_bce_step", logits.device, _hip.ptr(logits), logits.stride(0), logits.stride(1), logits.stride(2), _hip.ptr(labels),
+                 _hip.ptr(weight), ws[0], ws[1], ws[2], ws[3], B, H, W, _hip.ptr(loss), _hip.ptr(dl), float(grad_scale), _hip.ptr(mask), _hip.ptr(sc))
+        if need_grad:
+            ctx.save_for_backward(dl)
+        if mask is not None:
+            ctx.mark_non_differentiable(mask)
+            return loss, mask
+        return loss, torch.empty(0, dtype=torch.int64, device=logits.device)
+
+    @staticmethod
+    def backward(ctx, g, _gmask):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None, None
+
+
+def bce_argmax_step(preds, labels, weight=None, grad_scale=1.0, want_mask=True):
+    """Both halves of the step either side of the network in one kernel (trainer.py:60-82):
+         loss = BCEWithLogitsLoss(weight)(preds, [1 - y, y])      mask = preds.argmax(dim=1)
+    preds [B,2,H,W] (any view with unit last stride, e.g. the trainer's centre crop), labels int64 [B,1,H,W] or [B,H,W].
+    Returns (loss, mask | None); loss.backward() feeds the gradient the same pass produced."""
+    wstrides = None
+    if weight is not None:
+        weight, wstrides = _weight_strides(weight, preds)
+    loss, mask = _BCEStepFn.apply(preds, labels, weight, wstrides, grad_scale, want_mask)
+    return loss, (mask if want_mask else None)
+
+
 def bce_with_logits(logits, target, weight=None, grad_scale=1.0):
     """mean(weight * bce(logits, target)).  `weight` follows torch broadcasting against
     [B,2,H,W]: like the reference (trainer.py:72-75), a [B,H,W] map is right-aligned, i.e. its
     first axis meets the CLASS axis and must be 1 or 2 (quirk Q4) — other sizes raise."""
     wstrides = None
     if weight is not None:
-        weight = weight.to(logits.device, torch.float32).contiguous()
-        shape = (1,) * (4 - weight.dim()) + tuple(weight.shape)
-        st = (0,) * (4 - weight.dim()) + tuple(weight.stride())
-        wstrides = []
-        for d in range(4):
-            if shape[d] == logits.shape[d]:
-                wstrides.append(st[d])
-            elif shape[d] == 1:
-                wstrides.append(0)
-            else:
-                raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton "
-                                   "dimension %d" % (logits.shape[d], shape[d], d))
+        weight, wstrides = _weight_strides(weight, logits)
     return _BCEFn.apply(logits, target, weight, wstrides, grad_scale)
 
 

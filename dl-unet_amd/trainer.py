@@ -2,7 +2,7 @@
 (trainer.py:15) and epoch bookkeeping; the step body runs on the HIP path:
 
     forward            unet(images)                        -> libunet_hip unet_forward
-    loss (L1)          BCEWithLogitsLoss(weight=class map)  -> unet_bce_logits (fwd + grad in one pass)
+    loss (L1)          BCEWithLogitsLoss(weight=class map)  -> unet_bce_step (target from labels, fwd + grad in one pass)
     backward           loss.backward()                     -> unet_backward_stage x6 (+ RCCL all-reduce if DP)
     update (L3)        SGD(lr=1e-4, momentum=0.99)          -> unet_sgd_momentum
     prediction (L2)    preds.argmax(dim=1) + IoU/PE        -> unet_eval_masks (fused crop+argmax+counts)
@@ -48,9 +48,9 @@ def _step_loss(unet, images, labels, device, train):
     labels = labels.to(device)                                  # everything below stays on the device
     pad = int((preds.shape[-1] - labels.shape[-1]) / 2)
     preds = preds[:, :, pad:labels.shape[-1] + pad, pad:labels.shape[-1] + pad]
-    ll = hip_optim.onehot2(labels, preds)                       # [1-y, y] (trainer.py:63-66)
     weight_maps = class_balance(labels.squeeze(1))              # [B,H,W] (trainer.py:72), unet_class_balance
-    loss = hip_optim.bce_with_logits(preds, ll, weight=weight_maps)
+    # the one-hot target [1-y, y] (trainer.py:63-66) is formed inside the kernel from the integer labels
+    loss, _ = hip_optim.bce_argmax_step(preds, labels, weight=weight_maps, want_mask=False)
     return preds, loss, labels
 
 

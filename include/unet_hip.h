@@ -173,6 +173,15 @@ size_t unet_bce_scratch_bytes(size_t numel);
 int unet_bce_logits(const void *logits, const void *target, const void *weight,
                     long wsB, long wsC, long wsH, long wsW, int B, int H, int W,
                     void *loss_out, void *dlogits, float grad_scale, void *scratch, void *stream);
+/* L1 + L2 of a training step in one pass (trainer.py:60-82): logits [B,2,H,W] fp32 addressed through element strides
+ * (batch, class plane, row; unit pixel stride - the trainer's centre crop of preds is such a view), int64 labels [B,1,H,W]
+ * in {0,1} instead of the one-hot target [1-y, y], the optional weight as in unet_bce_logits.  Writes the mean loss, the
+ * dense dlogits [B,2,H,W] (x grad_scale; may be NULL) and the argmax mask [B,H,W] int64, ties -> class 0 (may be NULL).
+ * scratch: >= unet_bce_step_scratch_bytes(B*H*W). */
+size_t unet_bce_step_scratch_bytes(size_t npix);
+int unet_bce_step(const void *logits, long xsB, long xsC, long xsH, const void *labels_i64, const void *weight,
+                  long wsB, long wsC, long wsH, long wsW, int B, int H, int W, void *loss_out, void *dlogits,
+                  float grad_scale, void *mask_i64, void *scratch, void *stream);
 /* builds ll from integer labels on device: ll[:,0]=1-y, ll[:,1]=y (trainer.py:63-66) */
 int unet_onehot2(const void *labels_i64, void *target, int B, int H, int W, void *stream);
 

@@ -118,3 +118,101 @@ def branch_disagreements(masks, sels, S, B, seed_w=0, seed_x=1):
             gap = (win.max(axis=-1) - chosen)[diff]
             worst = max(worst, float(gap.max() / max(np.abs(a).max(), 1e-300)))
     return n_relu, n_pool, worst
+
+
+def shadow_training(net, train, val, epochs_arg, batch_size=2, lr=1e-4, mu=0.99, device=0):
+    """The trainer's step sequence (trainer.py:39-135: epochs_arg + 1 epochs of train batches with class-balanced
+    BCE-with-logits, backward, SGD(momentum), then the validation batches forward-only) run twice in lock step:
+      * on the HIP path through the module API (the same calls dl-unet_amd/trainer.py makes), and
+      * by the fp64 C oracle on its own fp64 weight trajectory, with every training forward/backward evaluated on the
+        ReLU / pool branch the HIP forward of that step took (validation is forward-only: the forward is continuous in
+        those decisions, so it needs no pinning).
+    `net` is modified (trained).  Returns (hip, ref, final): the six progress series of each side and the normalised
+    distance of the final HIP weights from the oracle's."""
+    import network  # noqa: F401
+    import optim as hip_optim
+    from functions import class_balance, metrics_from_counts
+    dev = torch.device("cuda", device)
+    names = [k for k, _ in net.named_parameters()]
+    p64 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in net.named_parameters()}
+    buf64 = {}
+    opt = hip_optim.SGD(net.parameters(), lr=lr, momentum=mu)
+    keys = ("loss", "loss_val", "train_eval_iou", "train_eval_pe", "val_eval_iou", "val_eval_pe")
+    hip = {k: [] for k in keys}
+    ref = {k: [] for k in keys}
+
+    def ref_weights(labels):
+        # functions.py:82-117 in the reference's own arithmetic: float32 count ratio, then widened (the loss is fp64)
+        lab = labels[:, 0]
+        w = np.empty(lab.shape, dtype=np.float32)
+        for b in range(lab.shape[0]):
+            uval, counts = np.unique(lab[b], return_counts=True)
+            for pos in range(len(uval)):
+                w[b][lab[b] == uval[pos]] = np.float32(counts[1]) / np.float32(counts[pos])
+        return w.astype(np.float64)
+
+    def ref_metrics(logits64, labels):
+        pred = oracle_c.argmax2(logits64)[0]
+        lab = labels[0, 0]
+        return float(np.logical_and(pred, lab).sum() / np.logical_or(pred, lab).sum()), float(np.abs(pred - lab).sum() / pred.size)
+
+    for _ in range(epochs_arg + 1):
+        tot_h = tot_r = 0.0
+        m_h = m_r = None
+        for images, labels in train:
+            x_np, lab_np = images.numpy(), labels.numpy()
+            B, _, S, _ = x_np.shape
+            opt.zero_grad()
+            logits = net(images.to(dev))
+            ctx = logits.grad_fn                                        # the autograd node of _UnetFunction holds the workspace
+            masks, sels = branch_of(net._get_handle(device), ctx.ws, B, S)
+            lab_d = labels.to(dev)
+            loss, _ = hip_optim.bce_argmax_step(logits, lab_d, weight=class_balance(lab_d.squeeze(1)), want_mask=False)
+            loss.backward()
+            opt.step()
+            tot_h += float(loss.item())
+            if m_h is None:
+                _, stats = hip_optim.crop_argmax_metrics(logits.detach(), lab_d)
+                i, u, d = [int(v) for v in stats[0].tolist()]
+                mm = metrics_from_counts(i, u, d, lab_np.shape[-1] * lab_np.shape[-2])
+                m_h = (float(mm[0, 0]), float(mm[1, 0]))
+            # the shadow
+            x64 = x_np.astype(np.float64)
+            lg64, _ = oracle_c.unet_fwd_bwd(p64, x64, relu_masks=masks, pool_sel=sels)
+            tgt = np.concatenate([1 - lab_np, lab_np], axis=1).astype(np.float64)
+            w64 = ref_weights(lab_np)                                   # [B,H,W] right-aligned against [B,2,H,W] (quirk Q4)
+            l64, dl64 = oracle_c.bce_logits(lg64, tgt, w=w64)
+            _, g64 = oracle_c.unet_fwd_bwd(p64, x64, dlogits=dl64, relu_masks=masks, pool_sel=sels)
+            first = not buf64
+            for k in names:
+                buf64[k] = g64[k].copy() if first else mu * buf64[k] + g64[k]
+                p64[k] = p64[k] - lr * buf64[k]
+            tot_r += float(l64)
+            if m_r is None:
+                m_r = ref_metrics(lg64, lab_np)
+        tv_h = tv_r = 0.0
+        v_h = v_r = None
+        with torch.no_grad():
+            for images, labels in val:
+                x_np, lab_np = images.numpy(), labels.numpy()
+                lab_d = labels.to(dev)
+                logits = net(images.to(dev))
+                tv_h += float(hip_optim.bce_argmax_step(logits, lab_d, weight=class_balance(lab_d.squeeze(1)), want_mask=False)[0].item())
+                if v_h is None:
+                    _, stats = hip_optim.crop_argmax_metrics(logits, lab_d)
+                    i, u, d = [int(v) for v in stats[0].tolist()]
+                    mm = metrics_from_counts(i, u, d, lab_np.shape[-1] * lab_np.shape[-2])
+                    v_h = (float(mm[0, 0]), float(mm[1, 0]))
+                lg64, _ = oracle_c.unet_fwd_bwd(p64, x_np.astype(np.float64))
+                tgt = np.concatenate([1 - lab_np, lab_np], axis=1).astype(np.float64)
+                l64, _ = oracle_c.bce_logits(lg64, tgt, w=ref_weights(lab_np), need_grad=False)
+                tv_r += float(l64)
+                if v_r is None:
+                    v_r = ref_metrics(lg64, lab_np)
+        for side, tot, totv, m, v in ((hip, tot_h, tv_h, m_h, v_h), (ref, tot_r, tv_r, m_r, v_r)):
+            side["loss"].append(tot / (len(train) * batch_size))
+            side["loss_val"].append(totv / (len(val) * batch_size))
+            side["train_eval_iou"].append(m[0]); side["train_eval_pe"].append(m[1])
+            side["val_eval_iou"].append(v[0]); side["val_eval_pe"].append(v[1])
+    final = max(nerr(v.detach().cpu().numpy(), p64[k]) for k, v in net.named_parameters())
+    return hip, ref, final

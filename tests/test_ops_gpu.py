@@ -275,6 +275,32 @@ def test_step_side_kernels(hip, golden_dir):
     tie = torch.zeros(1, 2, 4, 4, device="cuda"); am2 = torch.empty(1, 4, 4, dtype=torch.int64, device="cuda")
     hip.check(L.unet_argmax2(hip.ptr(tie), 32, 16, 4, hip.ptr(am2), 1, 4, 4, hip.stream()))
     assert int(am2.sum()) == 0                                               # ties -> class 0
+    # L1 + L2 fused (unet_bce_step): integer labels instead of the one-hot target, loss + gradient + argmax in one pass;
+    # the logits are a centre-cropped VIEW of a larger tensor, as in the trainer (trainer.py:60-61)
+    big = torch.full((B, 2, H + 4, W + 6), 123.0, device="cuda")
+    big[:, :, 2:2 + H, 3:3 + W] = lg
+    view = big[:, :, 2:2 + H, 3:3 + W]
+    sc2 = scratch(L.unet_bce_step_scratch_bytes(B * H * W))
+    for wptr, wstr, kl, kg in ((None, (0, 0, 0, 0), "bce_plain_loss", "bce_plain_grad"), (hip.ptr(wm), (0, H * W, W, 1), "bce_weighted_loss", "bce_weighted_grad")):
+        dx2 = torch.full_like(lg, -7.0); am3 = torch.full((B, H, W), -1, dtype=torch.int64, device="cuda")
+        hip.check(L.unet_bce_step(hip.ptr(view), view.stride(0), view.stride(1), view.stride(2), hip.ptr(labels), wptr, wstr[0], wstr[1], wstr[2], wstr[3],
+                                  B, H, W, hip.ptr(loss), hip.ptr(dx2), 1.0, hip.ptr(am3), hip.ptr(sc2), hip.stream()))
+        assert abs(loss.item() - float(ka[kl])) < 1e-5 * abs(float(ka[kl]))
+        assert nerr(dx2, torch.from_numpy(ka[kg])) < 1e-5
+        assert np.array_equal(am3.cpu().numpy(), ka["argmax_S220"])
+    # grad_scale, and the optional outputs left out
+    hip.check(L.unet_bce_step(hip.ptr(lg), 2 * H * W, H * W, W, hip.ptr(labels), None, 0, 0, 0, 0, B, H, W, hip.ptr(loss), hip.ptr(dx2), 0.25,
+                              None, hip.ptr(sc2), hip.stream()))
+    assert nerr(dx2, 0.25 * torch.from_numpy(ka["bce_plain_grad"])) < 1e-5
+    hip.check(L.unet_bce_step(hip.ptr(lg), 2 * H * W, H * W, W, hip.ptr(labels), None, 0, 0, 0, 0, B, H, W, hip.ptr(loss), None, 1.0,
+                              None, hip.ptr(sc2), hip.stream()))
+    assert abs(loss.item() - float(ka["bce_plain_loss"])) < 1e-5 * abs(float(ka["bce_plain_loss"]))
+    # module-level wrapper: loss.backward() delivers that gradient to the logits
+    import optim as hip_optim
+    lgr = lg.clone().requires_grad_(True)
+    l2, m2 = hip_optim.bce_argmax_step(lgr, labels, weight=wm)
+    l2.backward()
+    assert nerr(lgr.grad, torch.from_numpy(ka["bce_weighted_grad"])) < 1e-5 and np.array_equal(m2.cpu().numpy(), ka["argmax_S220"])
     # L3 SGD momentum, two steps, against torch.optim.SGD
     torch.manual_seed(0)
     ps = [torch.randn(n, device="cuda") for n in (5000, 3, 70001)]
