@@ -210,7 +210,7 @@ def split_line(full, detail_path=None):
     return line, full
 
 
-def cpu_baseline(budget_s=30.0, gpu_check=None):
+def cpu_baseline(budget_s=30.0, gpu_check=None, parity_bound=1e-3):
     """The reference's CPU path (torch restatement, validated against the imported reference by
     tests/test_oracle_golden.py) on a bounded sample, BASELINE.md section 4: B=1 fwd+bwd+SGD (>= 5 timed iterations) and
     forward-only on the host's share of cores; B=2 and 8 threads as far as the budget allows.
@@ -266,7 +266,8 @@ def cpu_baseline(budget_s=30.0, gpu_check=None):
         margin = np.abs(ref[:, 0] - ref[:, 1])
         safe = margin > 2e-5 * scale                                 # pixels whose CPU margin exceeds the forward tolerance
         same = (got[:, 1] > got[:, 0]) == (ref[:, 1] > ref[:, 0])
-        parity = {"max_abs_err_over_max_abs_ref": err, "bound": 1e-3, "ok": bool(err <= 1e-3 and same[safe].all()),
+        safe = margin > 2 * parity_bound * scale if parity_bound > 1e-3 else safe
+        parity = {"max_abs_err_over_max_abs_ref": err, "bound": parity_bound, "ok": bool(err <= parity_bound and same[safe].all()),
                   "argmax_equal_px": int(same.sum()), "px": int(same.size), "argmax_equal_where_margin_gt_tol": bool(same[safe].all())}
     head = run(share, 1, True, 5, min_iters=5)
     run(share, 1, False, 5, min_iters=3)
@@ -544,7 +545,9 @@ def run_rank(args):
                 chk = chk.to(dev)
                 with torch.no_grad():
                     return chk(torch.from_numpy(x_np).to(dev)).cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(gpu_check=gpu_logits)
+            # fp32 arithmetic: the north_star's 1e-3; bf16 tensors (mode 2, 8 significant bits per stored activation): the 5e-2 of
+            # tests/test_bf16_gpu.py's whole-net bound
+            out["cpu_baseline"] = cpu_baseline(gpu_check=gpu_logits, parity_bound=5e-2 if args.math == 2 else 1e-3)
     # informational: the same step in the other arithmetic modes (not part of `value`)
     if args.other_modes:
         other = {}

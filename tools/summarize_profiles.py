@@ -9,6 +9,8 @@ bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlin
 json.dump(bench, open("profiles/%s_bench.json" % tag, "w"), indent=1)
 shutil.copy(glob.glob(os.path.join(src, "stats/*/*kernel_stats.csv"))[0], "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
 shutil.copy(os.path.join(src, "launches.csv"), "profiles/%s_launches.csv" % tag)
+if os.path.exists(os.path.join(src, "bench_detail.json")):          # per-family / per-layer tables of the same run (bench.py --detail)
+    shutil.copy(os.path.join(src, "bench_detail.json"), "profiles/%s_bench_detail.json" % tag)
 
 def short(n):
     return n.split("(")[0].replace("void ", "").replace("unet::", "")[:44]
