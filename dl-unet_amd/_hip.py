@@ -23,6 +23,7 @@ _SIGS = {
     "unet_get_math": (C.c_int, []),
     "unet_set_lds_dma": (C.c_int, [C.c_int]),
     "unet_set_grad_scale": (C.c_int, [vp, C.c_float]),
+    "unet_set_overlap": (C.c_int, [C.c_int]),
     "unet_dp_unique_id": (C.c_int, [vp]),
     "unet_dp_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "unet_dp_destroy": (C.c_int, [vp]),

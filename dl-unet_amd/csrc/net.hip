@@ -74,6 +74,10 @@ struct unet_handle {
     int math;             // arithmetic of this handle's forwards (unet_config::math); -1 = the process default at each forward
     unet_dp *dp = nullptr;
     float grad_scale = 1.f;   // unet_set_grad_scale: the backward reads dlogits * grad_scale (data parallel: 1/world)
+    // opt-in (unet_set_overlap / UNET_OVERLAP=1): the weight gradients of a backward stage run on an auxiliary stream next to
+    // the dgrad chain (they only share dz); the streams re-join at the end of every stage
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // plans of the training forwards still awaiting their backward, keyed by workspace pointer
     std::mutex mu;
     std::vector<std::pair<void *, Plan>> live;
@@ -439,6 +443,11 @@ int unet_create(unet_handle **out, const unet_config *cfg)
 int unet_destroy(unet_handle *h)
 {
     if (h && h->dp) (void)unet_dp_free(h->dp);
+    if (h) {
+        if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    }
     delete h;
     return 0;
 }
@@ -448,6 +457,14 @@ int unet_set_grad_scale(unet_handle *h, float scale)
     ARG_CHECK(h, "unet_set_grad_scale: null handle");
     ARG_CHECK(scale > 0.f && scale <= 1.f, "unet_set_grad_scale: scale must be in (0, 1] (1/world), got %g", (double)scale);
     h->grad_scale = scale;
+    return 0;
+}
+
+static int g_overlap = [] { const char *e = getenv("UNET_OVERLAP"); return e ? atoi(e) : 0; }();
+int unet_set_overlap(int on)
+{
+    ARG_CHECK(on == 0 || on == 1, "unet_set_overlap: 0 or 1");
+    g_overlap = on;
     return 0;
 }
 
@@ -662,6 +679,31 @@ int unet_backward_stage_params(int stage, int *idx, int cap)
 
 #define GRAD(i) ((float *)grads[(i)])
 
+// Stream of the weight-gradient launches of the backward stage this thread is in: the caller's stream, or (overlap on) the
+// handle's auxiliary stream after it has been made to wait for everything enqueued on the caller's stream so far - so a
+// weight gradient must be enqueued BEFORE the dgrad it is to run next to.
+struct WgradStream {
+    unet_handle *h; hipStream_t main; bool overlap; bool used;
+    hipStream_t get()
+    {
+        if (!overlap) return main;
+        (void)hipEventRecord(h->ev_fork, main);
+        (void)hipStreamWaitEvent(h->aux, h->ev_fork, 0);
+        used = true;
+        return h->aux;
+    }
+    void join()
+    {
+        if (!used) return;
+        (void)hipEventRecord(h->ev_join, h->aux);
+        (void)hipStreamWaitEvent(main, h->ev_join, 0);
+        used = false;
+    }
+};
+static thread_local WgradStream *t_wst = nullptr;
+static inline hipStream_t wgrad_stream(hipStream_t st) { return t_wst ? t_wst->get() : st; }
+static inline hipStream_t wst_same(hipStream_t st) { return (t_wst && t_wst->overlap) ? t_wst->h->aux : st; }   // right after a wgrad_stream() call
+
 static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const void *const *params, void *const *grads,
                          int layer, const float *X, int XH, int C, const float *dz, int Ho, int K,
                          float *dx, const float *mask, const float *add)
@@ -672,7 +714,7 @@ static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const 
     {
         RowScope rs(layer, "wgrad");
         WgradP w = conv_wgrad_desc(X, XH, C, 0, dz, Ho, K, B, GRAD(2 * layer), C, 0, WS(pl.slab), pl.slab_bytes, GRAD(2 * layer + 1));
-        if ((rc = launch_wgrad(w, st))) return rc;
+        if ((rc = launch_wgrad(w, wgrad_stream(st)))) return rc;
     }
     if (dx) {
         RowScope rs(layer, "dgrad");
@@ -708,6 +750,17 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
     const int B = pl.B;
     const int *ch = pl.ch;
     int rc;
+    if (g_overlap && !h->aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    WgradStream wst{h, st, g_overlap != 0, false};
+    struct Scope {                           // every return path re-joins the streams before the caller sees the stage as enqueued
+        WgradStream &w;
+        explicit Scope(WgradStream &w_) : w(w_) { t_wst = &w; }
+        ~Scope() { w.join(); t_wst = nullptr; }
+    } scope(wst);
 
     if (stage < 4) {
         const int l = stage;
@@ -723,6 +776,15 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
                                 WS(pl.g_d1[l]), WS(pl.d1[l]), nullptr))) return rc;
         // conv_l1e: virtual concat input.  dgrad per source half (skip half only over the crop window)
         const int lay = C1E_L[l];
+        {
+            RowScope rs(lay, "wgrad");
+            WgradP ws_ = conv_wgrad_desc(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
+                                         GRAD(2 * lay), 2 * ch[l], 0, WS(pl.slab), pl.slab_bytes);
+            if ((rc = launch_wgrad(ws_, wgrad_stream(st)))) return rc;
+            WgradP wu = conv_wgrad_desc(WS(pl.u[l]), pl.eu[l], ch[l], 0, WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
+                                        GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes, GRAD(2 * lay + 1));
+            if ((rc = launch_wgrad(wu, wst_same(st)))) return rc;
+        }
         WLayer Ld = wl_dgrad(PARAM(2 * lay), ch[l], 2 * ch[l], WS(pl.wt_bwd[lay]));
         {
             RowScope rs(lay, "dgrad");
@@ -735,21 +797,17 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
             if ((rc = with_wino(du, WS(pl.wu_bwd[lay]) + wino_u_floats(ch[l], ch[l]), Ld, ch[l], 0, st))) return rc;
             if ((rc = launch_igemm(du, st))) return rc;
         }
-        {
-            RowScope rs(lay, "wgrad");
-            WgradP ws_ = conv_wgrad_desc(WS(pl.t[l]), pl.et[l], ch[l], pl.pad[l], WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
-                                         GRAD(2 * lay), 2 * ch[l], 0, WS(pl.slab), pl.slab_bytes);
-            if ((rc = launch_wgrad(ws_, st))) return rc;
-            WgradP wu = conv_wgrad_desc(WS(pl.u[l]), pl.eu[l], ch[l], 0, WS(pl.g_d1[l]), pl.ed1[l], ch[l], B,
-                                        GRAD(2 * lay), 2 * ch[l], ch[l], WS(pl.slab), pl.slab_bytes, GRAD(2 * lay + 1));
-            if ((rc = launch_wgrad(wu, st))) return rc;
-        }
         // upconv_l: input is d2[l+1] (or a2[4]); its dgrad is masked by that ReLU output
         {
             const int ul = UP_L[l];
             const int hin = pl.eu[l] / 2;
             const float *uin = l == 3 ? WS(pl.a2[4]) : WS(pl.d2[l + 1]);
             float *dzin = l == 3 ? WS(pl.g_a2[4]) : WS(pl.g_d2[l + 1]);
+            {
+                RowScope rs(ul, "wgrad");
+                WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes, GRAD(2 * ul + 1));
+                if ((rc = launch_wgrad(w, wgrad_stream(st)))) return rc;
+            }
             {
                 RowScope rs(ul, "dgrad");
                 if ((rc = pack_upconv_dgrad(PARAM(2 * ul), WS(pl.wt_bwd[ul]), ch[l + 1], ch[l], t_es, st))) return rc;
@@ -763,9 +821,6 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
                 d.math = pl.math;
                 if ((rc = launch_igemm(d, st))) return rc;
             }
-            RowScope rs(ul, "wgrad");
-            WgradP w = upconv_wgrad_desc(uin, hin, ch[l + 1], WS(pl.g_u[l]), ch[l], B, GRAD(2 * ul), WS(pl.slab), pl.slab_bytes, GRAD(2 * ul + 1));
-            if ((rc = launch_wgrad(w, st))) return rc;
         }
         return 0;
     }

@@ -449,6 +449,35 @@ def test_shape_sweep_forward_backward(net, B, S):
             assert ((yi[0] - y[i]).abs().max() / y.abs().max()).item() < FWD_TOL
 
 
+def test_overlap_knob_gives_bit_identical_gradients(net):
+    """unet_set_overlap(1): weight gradients on the handle's auxiliary stream next to the dgrad chain, re-joined at every stage
+    end.  Same kernels on the same data, only their interleaving differs: logits and all 46 gradients must be bit-identical
+    (any missing stream dependency shows up as a difference here or as a failure of the fp64 comparison at S=380)."""
+    import _hip
+    from oracle import parity, prng
+    L = _hip.lib()
+    x = torch.from_numpy(prng.make_input(1, 2, 252)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(2, (2, 2, 68, 68))).cuda()
+
+    def once():
+        net.zero_grad(set_to_none=True)
+        y = net(x)
+        y.backward(dl)
+        torch.cuda.synchronize()
+        return y.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    y0, g0 = once()
+    _hip.check(L.unet_set_overlap(1), "unet_set_overlap")
+    try:
+        for _ in range(3):                                   # repeated: a race would not lose every time
+            y1, g1 = once()
+            assert torch.equal(y0, y1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+        r = parity.check_same_branch(380, 1)
+        assert r["fwd"] < FWD_TOL and max(r["grads"].values()) < GRAD_TOL
+    finally:
+        _hip.check(L.unet_set_overlap(0), "unet_set_overlap")
+
+
 def test_rccl_communicator_behind_the_c_abi_single_rank(net):
     """unet_dp_* (csrc/dp.hip): unique id, ncclCommInitRank, broadcast, per-stage all-reduce on the communicator stream,
     join.  With one rank the collectives are identities, so the gradients must equal the plain backward bit for bit —

@@ -68,6 +68,44 @@ for key, sub in DOM:
         lines.append("rocprofv3 --stats (bench.py --steps 5 --warmup 2): %s avg launch %.4f ms over %d calls%s." %
                      (sub, ns[key] / calls[key] / 1e6, calls[key],
                       "; bench.py HIP events: %.4f ms" % bench["roofline"]["avg_launch_ms"] if key == bench_dom else ""))
+# ---- per-layer HBM traffic of the dominant MFMA families: counter bytes against algorithmic bytes -------------------
+# The PMC passes run whole steps (no instrumented pass), so the i-th dispatch of a kernel family within a step is the i-th
+# launch of that family in bench.py's per-launch table (same launch order every step).
+def per_layer_traffic(sub_kernel, kind_code, tagsub):
+    def series(passdir, counter):
+        f = glob.glob(os.path.join(src, passdir, "*/*counter_collection.csv"))[0]
+        seen = collections.OrderedDict()
+        for r in csv.DictReader(open(f)):
+            if sub_kernel in r["Kernel_Name"] and "transform" not in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                seen[int(r["Dispatch_Id"])] = seen.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+        return [seen[k] for k in sorted(seen)]
+    launches = [r for r in csv.DictReader(open(os.path.join(src, "launches.csv"))) if int(r["kind"]) == kind_code and tagsub in r["tag"]]
+    fe_s, wr_s = series("fetch", "FETCH_SIZE"), series("write", "WRITE_SIZE")
+    if not launches or not fe_s:
+        return []
+    steps_in_table = 3 if len(launches) % 3 == 0 else 1
+    per_step = len(launches) // steps_in_table
+    if per_step == 0 or len(fe_s) % per_step or len(wr_s) != len(fe_s):
+        return []
+    rows = []
+    for i in range(per_step):
+        l = launches[i]
+        f = 2 * sum(fe_s[i::per_step]) / (len(fe_s) // per_step) / 1024          # KB -> MB, x2 (gfx950 FETCH_SIZE)
+        w = sum(wr_s[i::per_step]) / (len(wr_s) // per_step) / 1024
+        alg = float(l["mbytes"])
+        extra = ""
+        if "tiles=" in l["tag"] and " N=" in l["tag"]:
+            tiles = int(l["tag"].split("tiles=")[1].split()[0]); n = int(l["tag"].split(" N=")[1].split()[0])
+            wgs = -(-tiles // 64) * (n // 32)
+            extra = " | %d | %.2f" % (wgs, wgs / 512.0)
+        rows.append("| %s | %.3f | %.1f | %.1f | %.2f%s |" % (l["row"], float(l["ms"]), alg, f + w, (f + w) / alg if alg else 0.0, extra))
+    return rows
+
+for title, subk, kind_code, tagsub, hdr in (("wino32_f32_kernel", "wino32", 3, "wino32", " | workgroups | rounds of 512"), ("igemmb_kernel", "igemmb", 0, "igemmb", "")):
+    rows = per_layer_traffic(subk, kind_code, tagsub)
+    if rows:
+        lines += ["", "## %s: HBM bytes per launch, counters (FETCH_SIZE x2 + WRITE_SIZE) against algorithmic (SURVEY 8d)" % title, "",
+                  "| launch | ms | algorithmic MB | counter MB | counter / algorithmic%s |" % hdr, "|---|---|---|---|---|" + ("---|---|" if hdr else "")] + rows
 open("profiles/%s_pmc_summary.md" % tag, "w").write("\n".join(lines) + "\n")
 allm = {}
 if os.path.exists("profiles/pmc_traffic.json"):
