@@ -718,3 +718,26 @@ def test_config3_arithmetic_at_its_real_size(math_mode):
         acc = part if acc is None else [a + b for a, b in zip(acc, part)]
     for a, b in zip(acc, g_all):
         assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < 1e-3     # same bf16 products, fp32 sums in another order
+
+
+def test_bench_self_launch_two_ranks_on_this_gpu(tmp_path):
+    """`python3 bench.py --gpus 2` without WORLD_SIZE: the launcher starts both ranks itself (child processes), rank 0's line
+    is relayed.  With --share-gpu both ranks use this box's one GPU over gloo (RCCL refuses two ranks on a device), which
+    exercises the launch path, the per-module data-parallel handle, the 1/world gradient scale and the bucket logic on
+    hardware; the driver's multi-GPU runs take the same path with one device per rank and the RCCL communicator."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    detail = os.path.join(tmp_path, "detail.json")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "1",
+                          "--detail", detail], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 2048, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["comm"]["self_launched"] is True and d["comm"]["ranks"] == 2 and "gloo" in d["comm"]["gradient_allreduce"]
+    assert d["value"] > 0 and "roofline" in d and "cpu_baseline" not in d            # the CPU baseline belongs to the N = 1 line
+    assert len(json.load(open(detail))["layers"]) > 50
