@@ -11,7 +11,8 @@
 // set-up, first-stage latency, epilogue and barrier stalls hide behind each other's MFMAs); a wave owns 16 tiles x 32
 // channels for all 16 xi -> 16*2 accumulators of 16x16 (128 VGPRs):
 //   * tiles are numbered linearly over (image, tile row, tile column): no 2-D edge waste, only the last workgroup
-//     of a launch is ragged;
+//     of a launch is ragged; consecutive workgroups are the n-tiles of one m-tile (they are resident together on an XCD
+//     and re-read one patch image from its L2: HBM traffic of the family -34 % against n-major order, step -0.7 %);
 //   * per K step (8 channels) the workgroup stages by LDS-DMA (buffer descriptors: fixed per-lane offsets, the channel
 //     step in the scalar offset, pixels outside the tensor through the range check)  (a) an 18 KiB patch image — each
 //     tile's two own pixel columns; columns 2,3 are the right neighbour's, or a per-tile-row "tail" — and (b) the

@@ -48,7 +48,7 @@ typedef struct unet_config {
 } unet_config;
 
 const char *unet_last_error(void);
-int unet_abi_version(void);
+int unet_abi_version(void);     /* 3.  (2: unet_config::math, unet_dp_*;  3: unet_bce_step, unet_set_grad_scale, unet_set_overlap) */
 
 /* Arithmetic of the dense contractions — the process default, used by the per-op entry points and by handles created
  * with math = -1 (read when a forward is planned; its backward keeps that forward's mode):
