@@ -237,3 +237,26 @@ def test_bench_launcher_relays_rank0_line_and_exit_codes(tmp_path):
     t0 = __import__("time").time()
     bad = subprocess.run([sys.executable, runner, "fail"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 7 and bad.stdout.strip() == "" and __import__("time").time() - t0 < 30
+
+
+def test_bench_tables_from_a_synthetic_launch_dump():
+    """bench.layer_table / comm_table on a hand-made per-launch dump: row aggregation, the two roofs, which one binds, SURVEY
+    row mapping, per-bucket all-reduce time and the exposed wait."""
+    import bench
+    rows = [
+        {"kind": "3", "ms": "0.5", "gflop": "180.0", "exec_gflop": "80.0", "mbytes": "400.0", "row": "conv22c.fwd", "tag": "wino32<1> M=1 N=128 Kd=1152 nsrc=1 tiles=9"},
+        {"kind": "3", "ms": "0.5", "gflop": "180.0", "exec_gflop": "80.0", "mbytes": "400.0", "row": "conv22c.fwd", "tag": "wino32<1> M=1 N=128 Kd=1152 nsrc=1 tiles=9"},
+        {"kind": "5", "ms": "0.25", "gflop": "0.0", "exec_gflop": "0.0", "mbytes": "1200.0", "row": "pool1.bwd", "tag": "maxpool2_bwd"},
+        {"kind": "6", "ms": "0.4", "gflop": "0.0", "exec_gflop": "0.0", "mbytes": "100.0", "row": "allreduce", "tag": "allreduce n=1000 world=8"},
+        {"kind": "6", "ms": "0.6", "gflop": "0.0", "exec_gflop": "0.0", "mbytes": "100.0", "row": "allreduce", "tag": "allreduce n=1000 world=8"},
+        {"kind": "6", "ms": "0.3", "gflop": "0.0", "exec_gflop": "0.0", "mbytes": "0.0", "row": "allreduce", "tag": "join (exposed wait of the compute stream)"},
+    ]
+    t = {r["row"]: r for r in bench.layer_table([r for r in rows if r["kind"] != "6"], 2, 3)}
+    c = t["conv22c.fwd"]
+    assert c["survey"] == "A5" and c["kernels"] == ["wino32"] and abs(c["ms_per_step"] - 0.5) < 1e-12 and c["launches_per_step"] == 1.0
+    assert abs(c["mfma_frac"] - (160e9 / 157.3e12) / 1e-3) < 1e-9 and c["bound"] == "mfma" and abs(c["hbm_frac"] - 0.1) < 1e-9
+    pl = t["pool1.bwd"]
+    assert pl["survey"] == "A3" and pl["bound"] == "hbm" and abs(pl["hbm_frac"] - (1200e6 / 8e12) / 0.25e-3) < 1e-9
+    cm = bench.comm_table(rows, 2)
+    assert abs(cm["allreduce_ms_per_step"] - 0.5) < 1e-12 and abs(cm["exposed_ms_per_step"] - 0.15) < 1e-12
+    assert len(cm["buckets"]) == 1 and abs(cm["buckets"][0]["gb_per_s"] - 0.1 / 0.5e-3) < 1e-6
