@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libunet_hip.so")
+_SO = os.environ.get("UNET_SO") or os.path.join(_HERE, "libunet_hip.so")
 _lib = None
 
 N_PARAMS = 46

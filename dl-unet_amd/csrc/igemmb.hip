@@ -76,7 +76,9 @@ __device__ __forceinline__ void igemmb_rows_linear(const IgemmP &p, int m0, int 
 
 // TN = 32-column tiles per wave; the wave's tile rows start at `wrow0` of the workgroup tile, its columns at n0w.
 // The row tables must be complete (barrier) before the call; `patch` is the wave's private LDS area (EPB_WAVE_BYTES).
-template <int TN>
+// PF = row passes whose +add / mask operands are prefetched together (all of a slab's by default; the register-resident-filter
+// kernel below has fewer registers to spare)
+template <int TN, int PF = 0>
 __device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][TN], int wrow0, int n0w, int lane, float *patch,
                                              const unsigned *rowoff, const unsigned char *rflag)
 {
@@ -111,13 +113,16 @@ __device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][T
     for (int tm = 0; tm < 2; ++tm) {
         // the slab's +add / ReLU' mask operands first, all of them: their latency runs under the LDS transpose (issued one per
         // row pass inside the store loop they serialise against the stores - the compiler cannot prove dst != add/mask)
-        constexpr int NP = 32 / RPP;
+        constexpr int NPA = 32 / RPP;                         // row passes of the slab
+        constexpr int NP = PF > 0 && PF < NPA ? PF : NPA;     // ... handled per chunk
         size_t o[NP];
         unsigned char fl[NP];
         uint4 ta[NP], tk[NP];
 #pragma unroll
+      for (int k0 = 0; k0 < NPA; k0 += NP) {
+#pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int trow = wrow0 + tm * 32 + rrow + RPP * k;
+            const int trow = wrow0 + tm * 32 + rrow + RPP * (k0 + k);
             o[k] = (size_t)rowoff[trow] + (size_t)coloff;
             fl[k] = rflag[trow];
         }
@@ -129,14 +134,16 @@ __device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][T
 #pragma unroll
             for (int k = 0; k < NP; ++k) tk[k] = *(const uint4 *)(maskp + o[k]);
         }
+        if (k0 == 0) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPB_PITCH + tn * 32 + l31] = acc[tm][tn][r] + bv[tn];
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPB_PITCH + tn * 32 + l31] = acc[tm][tn][r] + bv[tn];
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int prow = rrow + RPP * k;
+            const int prow = rrow + RPP * (k0 + k);
             const f32x4 lo = *(const f32x4 *)(patch + prow * EPB_PITCH + 8 * cg);
             const f32x4 hi = *(const f32x4 *)(patch + prow * EPB_PITCH + 8 * cg + 4);
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -168,6 +175,7 @@ __device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][T
                 *(uint4 *)(dstp + o[k]) = w;
             }
         }
+      }
     }
 }
 
@@ -335,6 +343,358 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
     igemmb_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
 }
 
+// =========================================================================================================================
+// convb64: the 64-input-channel 3x3 layers (conv12c, conv21c, conv12e forward; conv12c, conv11e, conv12e dgrad) with bf16
+// tensors.  K = 9 x 64 is nine steps of the kernel above - less time than a workgroup costs around them - and every input
+// pixel is staged once per tap and per n-tile: those launches sit at 0.25-0.3 of the HBM roof that binds them.  Here
+//   * a workgroup is PERSISTENT over output tiles of 8 x 32 pixels x 64 output channels, one workgroup per CU, ONE WAVE PER
+//     SIMD with the whole 512-entry register file;
+//   * its 64 x 576 filter block (72 KiB) is staged once by LDS-DMA and stays in LDS ([tap][n][64 channels], 16-byte chunks
+//     XOR-swizzled);
+//   * per tile the 10 x 34 input halo is fetched ONCE for all nine taps - by plain buffer loads into registers at the top of
+//     the previous tile's MFMA loop, written to the other LDS buffer after it.  (LDS-DMA costs a wave ~300 cycles of issue per
+//     instruction, 11 per tile; with one wave per SIMD nobody else feeds the matrix pipe meanwhile: measured 3300 of a tile's
+//     13700 cycles.  A load into registers issues in a few cycles, and a lone wave has the registers to park a whole halo.)
+//     Pixel rows of 128 B, chunks swizzled by the halo pixel index: the 32 pixels of an MFMA tile are consecutive halo pixels
+//     for every tap shift -> conflict-free ds_read_b128;
+//   * a wave owns two tile rows of 32 pixels x 64 channels.  The MFMA runs TRANSPOSED - A = filters, B = pixels - so that in
+//     the C/D layout a lane holds, for its pixel, groups of 4 consecutive output channels: bias / ReLU / ReLU' mask / +add
+//     and the bf16 rounding happen in registers and the result is stored from there in 8-byte pieces.  No LDS transpose,
+//     no second barrier: the LDS-staged epilogue of the kernel above cost this one 4000 of 13700 cycles (a dependent chain
+//     of LDS round trips that a lone wave cannot hide).
+// One barrier per tile.  The MFMA loop itself (36 steps of 4 ds_read_b128 + 4 MFMAs, fragments requested two steps ahead)
+// runs at 33 cycles per MFMA (tools/mfma_bf16_lds.hip: 34.8 for this mix on its own).
+// =========================================================================================================================
+#ifndef CB64_DEPTH
+#define CB64_DEPTH 3
+#endif
+struct CB64P {
+    IgemmP p;
+    int tx_n, ty_n, tiles;       // tiles per row / per column / in total (all images)
+    int dbg;                     // UNET_CB64_DBG & 8: in-kernel cycle stamps per phase (workgroup 0, wave 0)
+    FastDiv d_tpi, d_tx;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    const f32x2v f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned v)
+{
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+
+template <int TH, int TW>
+struct CB64Geom {
+    static constexpr int HWp = TW + 2, HHp = TH + 2, NPIX = HHp * HWp;
+    static constexpr int NINST = (NPIX + 7) / 8;               // 1-KiB pieces of a halo (8 pixels of 128 B each)
+    static constexpr int HALO_BYTES = NINST * 1024;
+    static constexpr int W_BYTES = 9 * 64 * 128;               // 73728
+    static constexpr int LDS = 2 * HALO_BYTES + W_BYTES;       // [halo 0][halo 1][filters]
+    static constexpr int NII = (NINST + 3) / 4;                // pieces per wave
+    static_assert(LDS <= 160 * 1024, "one workgroup per CU");
+};
+
+__device__ unsigned long long g_cb64_stamps[8];      // UNET_CB64_DBG & 8: cycles per phase (timing experiments)
+
+template <int TH, int TW, bool HAS_ADD, bool HAS_MASK>
+__global__ __launch_bounds__(256, 1) void convb64_kernel(const CB64P k)
+{
+    using G = CB64Geom<TH, TW>;
+    static_assert(TH == 8 && TW == 32, "a wave owns two tile rows of 32 pixels: each is one MFMA column block");
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    auto mark = [&](int i) { const unsigned long long now = __builtin_readcyclecounter(); stamp[i] += now - tprev; tprev = now; };
+    const IgemmP &p = k.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = p.Nn >> 6;
+    const int nb = blockIdx.x % nblk, wg = blockIdx.x / nblk, nwg = gridDim.x / nblk;
+    const int n0 = nb * 64;
+    const GSrc &g0 = p.src[0];
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, p.buf_bytes[2], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)g0.p, 0, p.buf_bytes[0], 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tpi = k.tx_n * k.ty_n;
+
+    // ---- halo roles, fixed for the kernel: piece i = wave + 4 ii covers halo pixels 8i .. 8i+7; lane -> (pixel P, 16-byte slot
+    // holding channel chunk slot ^ swz(P)).  hrel = byte offset of that piece relative to the halo's first pixel, hpos =
+    // (hy << 8 | hx), or -1 past the halo's end.  Per tile only the base offset and - on border tiles - the in-tensor test remain.
+    int hrel[G::NII], hpos[G::NII];
+    {
+        const int sub = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int ii = 0; ii < G::NII; ++ii) {
+            const int P = 8 * (wave + 4 * ii) + sub;
+            const int hy = P / G::HWp, hx = P - hy * G::HWp;
+            const int c = slot ^ ((P >> 1) & 7);
+            hrel[ii] = ((hy * g0.W + hx) * g0.C + c * 8) * 2;
+            hpos[ii] = (P < G::NPIX && wave + 4 * ii < G::NINST) ? (hy << 8 | hx) : -1;
+        }
+    }
+    struct TileGeo { int img, tyb, txb, iy0, ix0, base; bool interior; };
+    auto tile_geo = [&](int t) {
+        TileGeo q;
+        q.img = fdiv(t, k.d_tpi);
+        const int trem = t - q.img * tpi;
+        q.tyb = fdiv(trem, k.d_tx);
+        q.txb = trem - q.tyb * k.tx_n;
+        q.iy0 = q.tyb * TH + p.oy0 - g0.pad; q.ix0 = q.txb * TW + p.ox0 - g0.pad;
+        q.base = (((q.img * g0.H + q.iy0) * g0.W + q.ix0) * g0.C + g0.c0) * 2;            // may be "negative" on border tiles
+        q.interior = q.iy0 >= 0 && q.ix0 >= 0 && q.iy0 + G::HHp <= g0.H && q.ix0 + G::HWp <= g0.W;
+        return q;
+    };
+    u32x4 hreg[G::NII];                  // the next tile's halo pieces on their way from memory to LDS
+    auto halo_load = [&](const TileGeo &q, bool live) {
+#pragma unroll
+        for (int ii = 0; ii < G::NII; ++ii) {
+            bool ok = live && hpos[ii] >= 0;
+            if (!q.interior) {
+                const int iy = q.iy0 + (hpos[ii] >> 8), ix = q.ix0 + (hpos[ii] & 255);
+                ok = ok && (unsigned)iy < (unsigned)g0.H && (unsigned)ix < (unsigned)g0.W;
+            }
+            hreg[ii] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? q.base + hrel[ii] : OOB, 0, 0);     // zeros outside the tensor
+        }
+    };
+    auto halo_store = [&](unsigned char *hl) {
+#pragma unroll
+        for (int ii = 0; ii < G::NII; ++ii)
+            if (wave + 4 * ii < G::NINST) *(u32x4 *)(hl + (wave + 4 * ii) * 1024 + lane * 16) = hreg[ii];
+    };
+
+    // ---- filters, once, resident in LDS behind the halo buffers: [tap][n][128 B], rows 8i .. 8i+7 per instruction, chunks
+    // swizzled by the row's n (the barrier in front of the tile loop publishes them)
+    unsigned char *wl = smem + 2 * G::HALO_BYTES;
+    {
+        const int sub = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int ii = 0; ii < 18; ++ii) {
+            const int i = wave + 4 * ii;
+            const int R = 8 * i + sub;
+            const int tap = R >> 6, n = R & 63;
+            const int c = slot ^ ((n >> 1) & 7);
+            bbuf_lds16(rs_w, wl + i * 1024, ((n0 + n) * p.ldw + tap * 64 + c * 8) * 2, 0);
+        }
+    }
+    int bw[2];                           // filter fragment base of n-block nbk (without tap / k step): row n = 32 nbk + l31
+#pragma unroll
+    for (int nbk = 0; nbk < 2; ++nbk) {
+        const int n = 32 * nbk + l31;
+        bw[nbk] = n * 128 + ((lh ^ ((n >> 1) & 7)) << 4);
+    }
+    // halo pixel of this lane's pixel in column block j (tile row 2 wave + j, column l31) at tap (0,0)
+    int pj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pj[j] = (2 * wave + j) * G::HWp + l31;
+    // epilogue role = the C/D layout of the transposed product: lane (pixel l31, half lh) holds output channels
+    // 32 nbk + 8 g + 4 lh + {0..3} in accumulator registers 4 g .. 4 g + 3 of acc[nbk][j]
+    float bv[2][4][4];
+#pragma unroll
+    for (int nbk = 0; nbk < 2; ++nbk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[nbk][g][c] = p.bias ? p.bias[n0 + 32 * nbk + 8 * g + 4 * lh + c] : 0.f;
+    const u16 *addp = (const u16 *)p.add, *maskp = (const u16 *)p.mask;
+    u16 *dstp = (u16 *)p.dst;
+
+    int t = wg, it = 0;
+    if (t < k.tiles) {
+        halo_load(tile_geo(t), true);
+        halo_store(smem);
+    }
+    __syncthreads();                       // first halo (written above) and the filters (vmcnt(0)) are in LDS
+    for (; t < k.tiles; t += nwg, ++it) {
+        const int cur = it & 1;
+        unsigned char *hl = smem + cur * G::HALO_BYTES;
+        const bool more = t + nwg < k.tiles;
+        const TileGeo qc = tile_geo(t);
+        halo_load(tile_geo(more ? t + nwg : t), more);        // lands in registers while the MFMA loop runs
+
+        // destination (element offsets; the launcher checks the tensor against 2^31 elements) of the lane's pixel in the wave's
+        // two tile rows, and the ReLU' mask / +add operands of its 2 x 8 channel groups: requested now, used after the loop
+        unsigned eo[2];
+        bool ev[2];
+        u32x2 tk[2][2][4], ta[2][2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int oy = qc.tyb * TH + 2 * wave + j, ox = qc.txb * TW + l31;
+            ev[j] = oy < p.OH && ox < p.OW;
+            oy = oy < p.OH ? oy : p.OH - 1; ox = ox < p.OW ? ox : p.OW - 1;
+            eo[j] = (unsigned)((qc.img * p.DH + oy) * p.DW + ox) * (unsigned)p.DC + (unsigned)(p.dn0 + n0);
+#pragma unroll
+            for (int nbk = 0; nbk < 2; ++nbk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (HAS_MASK) tk[j][nbk][g] = *(const u32x2 *)(maskp + eo[j] + 32 * nbk + 8 * g + 4 * lh);
+                    if (HAS_ADD) ta[j][nbk][g] = *(const u32x2 *)(addp + eo[j] + 32 * nbk + 8 * g + 4 * lh);
+                }
+        }
+
+        f32x16 acc[2][2];                  // [nbk][j]: rows = output channels, columns = pixels; starts at the bias
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[i][r >> 2][r & 3];
+        if (k.dbg & 8) mark(0);            // set-up of the tile
+
+        // ---- 36 steps (9 taps x 4 k steps of 16 channels), fully unrolled.  One wave per SIMD: nobody else hides the LDS
+        // latency, so the fragments of step s + DEPTH - 1 are requested before the 4 MFMAs of step s issue
+        constexpr int DEPTH = CB64_DEPTH;
+        bf16x8 fa[DEPTH][2], fb[DEPTH][2];
+        auto read_frags = [&](int st, int slot) {
+            const int tap = st >> 2, x = (st & 3) << 5;
+            const int ty = tap / 3, tx = tap - 3 * ty;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int P = pj[j] + (ty * G::HWp + tx);
+                fa[slot][j] = *(const bf16x8 *)(hl + ((P * 128 + ((lh ^ ((P >> 1) & 7)) << 4)) ^ x));
+            }
+#pragma unroll
+            for (int nbk = 0; nbk < 2; ++nbk) fb[slot][nbk] = *(const bf16x8 *)(wl + ((bw[nbk] + tap * 8192) ^ x));
+        };
+#pragma unroll
+        for (int st = 0; st < DEPTH - 1; ++st) read_frags(st, st);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            if (st + DEPTH - 1 < 36) read_frags(st + DEPTH - 1, (st + DEPTH - 1) % DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nbk = 0; nbk < 2; ++nbk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[nbk][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st % DEPTH][nbk], fa[st % DEPTH][j], acc[nbk][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k.dbg & 8) mark(1);            // MFMA loop
+
+        // ---- the next tile's halo: registers -> the other buffer (every wave finished reading it before the last barrier)
+        halo_store(smem + (cur ^ 1) * G::HALO_BYTES);
+        if (k.dbg & 8) mark(2);            // wait for the loads + LDS writes
+
+        // ---- epilogue in registers: +add, ReLU, ReLU' mask, one rounding to bf16.  A lane holds 4-channel groups 8 g + 4 lh
+        // of its pixel; v_permlane32_swap exchanges groups with the lane of the other half so that each ends up with two runs
+        // of 8 consecutive channels: 16-byte stores (lh = 0: channels 0-7 and 16-23 of the n-block, lh = 1: 8-15 and 24-31)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nbk = 0; nbk < 2; ++nbk) {
+                unsigned d[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = acc[nbk][j][4 * g + c];
+                    if (HAS_ADD) {
+                        const unsigned w0 = ta[j][nbk][g].x, w1 = ta[j][nbk][g].y;
+                        v[0] += bf2f((u16)(w0 & 0xffff)); v[1] += bf2f((u16)(w0 >> 16));
+                        v[2] += bf2f((u16)(w1 & 0xffff)); v[3] += bf2f((u16)(w1 >> 16));
+                    }
+                    if (HAS_MASK) {
+                        // a ReLU output: positive iff its bf16 pattern is neither zero nor negative
+                        const unsigned w0 = tk[j][nbk][g].x, w1 = tk[j][nbk][g].y;
+                        v[0] = (short)(w0 & 0xffff) > 0 ? v[0] : 0.f; v[1] = (short)(w0 >> 16) > 0 ? v[1] : 0.f;
+                        v[2] = (short)(w1 & 0xffff) > 0 ? v[2] : 0.f; v[3] = (short)(w1 >> 16) > 0 ? v[3] : 0.f;
+                    }
+                    // one v_cvt_pk_bf16_f32 per pair (RNE); ReLU on the packed result: a negative bf16 is a negative int16, and
+                    // rounding is monotone and keeps the sign, so max(round(x), 0) == round(max(x, 0))
+                    d[g][0] = cvt_pk_bf16(v[0], v[1]);
+                    d[g][1] = cvt_pk_bf16(v[2], v[3]);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { d[g][0] = pk_relu_bf16(d[g][0]); d[g][1] = pk_relu_bf16(d[g][1]); }
+                }
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        // lanes 32-63 of d[2gp] <-> lanes 0-31 of d[2gp+1]
+                        const auto r = __builtin_amdgcn_permlane32_swap(d[2 * gp][w], d[2 * gp + 1][w], false, false);
+                        d[2 * gp][w] = r[0]; d[2 * gp + 1][w] = r[1];
+                    }
+                if (ev[j]) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        u32x4 w = {d[2 * gp][0], d[2 * gp][1], d[2 * gp + 1][0], d[2 * gp + 1][1]};
+                        *(u32x4 *)(dstp + eo[j] + 32 * nbk + 16 * gp + 8 * lh) = w;
+                    }
+                }
+            }
+        if (k.dbg & 8) mark(3);            // epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's halo writes are in LDS
+        __builtin_amdgcn_s_barrier();                              // (no vmcnt wait: the stores stay in flight)
+        if (k.dbg & 8) mark(4);            // barrier
+    }
+    if ((k.dbg & 8) && blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_cb64_stamps[i], stamp[i]);
+        atomicAdd(&g_cb64_stamps[7], 1ull);
+    }
+}
+
+static bool convb64_applicable(const IgemmP &p)
+{
+    return p.T == 9 && p.TX == 3 && p.stride == 1 && p.nsrc == 1 && p.src[0].nch == 64 && p.Kd == 576 && p.Nn % 64 == 0 &&
+           !p.scatter && !(p.rw1 > p.rw0) && !p.pool_dst && p.DH == p.OH && p.DW == p.OW;
+}
+
+template <int TH, int TW, bool HAS_ADD, bool HAS_MASK>
+static int launch_convb64_t(const IgemmP &p, hipStream_t st)
+{
+    using G = CB64Geom<TH, TW>;
+    static bool attr_done[64] = {false};
+    auto kern = convb64_kernel<TH, TW, HAS_ADD, HAS_MASK>;
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, G::LDS, attr_done)) return rc_;
+    CB64P k;
+    k.p = p;
+    k.tx_n = cdiv(p.OW, TW); k.ty_n = cdiv(p.OH, TH);
+    k.tiles = p.NB * k.tx_n * k.ty_n;
+    k.d_tpi = make_fastdiv((unsigned)(k.tx_n * k.ty_n));
+    k.d_tx = make_fastdiv((unsigned)k.tx_n);
+    static const int dbg = [] { const char *e = getenv("UNET_CB64_DBG"); return e ? atoi(e) : 0; }();
+    k.dbg = dbg;
+    const int nblk = p.Nn / 64;
+    int cus = 256;
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    }
+    int per = k.tiles < cus ? k.tiles : cus;          // persistent workgroups per n-block: one per CU
+    char tag[96];
+    snprintf(tag, sizeof(tag), "convb64<%d;%d> M=%d N=%d tiles=%d wgs=%d pad=%d", TH, TW, p.M, p.Nn, k.tiles, per * nblk, p.src[0].pad);
+    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * (double)k.tiles * (TH * TW) * p.Nn * 576.0, igemm_alg_bytes(p) / 2.0);
+    hipLaunchKernelGGL(kern, dim3(per * nblk), dim3(256), G::LDS, st, k);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    if (dbg & 8) {
+        unsigned long long h[8];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cb64_stamps), sizeof(h)));
+        fprintf(stderr, "cb64 stamps %s: setup %llu mfma %llu halo-write %llu epilogue %llu barrier %llu (cycles, cumulative over %llu launches)\n", tag, h[0], h[1], h[2], h[3], h[4], h[7]);
+    }
+    return 0;
+}
+
+template <int TH, int TW>
+static int launch_convb64(const IgemmP &p, hipStream_t st)
+{
+    if (p.add && p.mask) return launch_convb64_t<TH, TW, true, true>(p, st);
+    if (p.add) return launch_convb64_t<TH, TW, true, false>(p, st);
+    if (p.mask) return launch_convb64_t<TH, TW, false, true>(p, st);
+    return launch_convb64_t<TH, TW, false, false>(p, st);
+}
+
 template <int BM, int BN, bool PAD>
 static int launch_cfgb(const IgemmP &p, hipStream_t st)
 {
@@ -375,6 +735,10 @@ int launch_igemmb(IgemmP p, bool pad, hipStream_t st)
         const size_t b = (size_t)p.Nn * p.ldw * 2;
         ARG_CHECK(b < 0x7FFFFFFFull, "igemmb: filter matrix exceeds 2 GiB");
         p.buf_bytes[2] = (int)b;
+    }
+    static const int use_cb64 = [] { const char *e = getenv("UNET_CONVB64"); return e ? atoi(e) : 1; }();
+    if (use_cb64 && convb64_applicable(p)) {
+        return launch_convb64<8, 32>(p, st);
     }
     if (p.Nn % 128 == 0) return pad ? launch_cfgb<128, 128, true>(p, st) : launch_cfgb<128, 128, false>(p, st);
     return pad ? launch_cfgb<256, 64, true>(p, st) : launch_cfgb<256, 64, false>(p, st);
