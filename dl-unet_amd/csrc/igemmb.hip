@@ -19,6 +19,15 @@
 // after each barrier.  It was removed; DESIGN.md section 4c has the numbers.  Also measured and dropped: issuing the next stage's
 // LDS-DMA in quarters between the MFMA groups instead of in one burst after the barrier (+6 % time), a second stage of prefetch,
 // and 32-channel K steps with 64-byte LDS rows (tools/ldsdma_depth.hip: the L2 -> LDS path moves 64-byte pieces at 2/3 the rate).
+// Round 3, the epilogue: it costs 19 % of the family's time (skipping it: 5.28 -> 4.25 ms per step).  Two replacements built on the
+// transposed product (A = filter rows, B = pixels: a lane then holds 4-channel groups of ITS pixel, see convb64 below), both
+// correct on every bf16 test, neither kept: (a) all in registers - v_cvt_pk_bf16_f32, v_permlane32_swap, 16-byte stores, no LDS,
+// no barrier: +5 % time (conv22c dgrad 0.219 -> 0.247 ms, upconv1 0.082 -> 0.114): a store instruction then touches 32 pixel rows
+// with 32 bytes each instead of 8 whole rows; (b) packed bf16 through an 8 KiB LDS patch per wave in [pixel][channel] order, read
+// back in memory order - 8 ds_write_b128 + 8 ds_read_b128 per lane instead of 64 ds_write_b32 + 32 ds_read_b128, the same
+// whole-row stores, mask applied to the packed rows: -0.6 % on the family in a same-box A/B (3x3 forwards -2...-4 %, up-conv
+// forwards +3...+10 %, some dgrads +6...+9 %).  With two workgroups per CU what the epilogue costs is its place at the end of a
+// workgroup's life, not its LDS instruction count.
 #include "common.hpp"
 #include "igemm_epilogue.hpp"
 #include <cstdio>
