@@ -371,6 +371,10 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
 //     and the bf16 rounding happen in registers and the result is stored from there in 8-byte pieces.  No LDS transpose,
 //     no second barrier: the LDS-staged epilogue of the kernel above cost this one 4000 of 13700 cycles (a dependent chain
 //     of LDS round trips that a lone wave cannot hide).
+// Cycle stamps of a tile (conv12c forward, 40 tiles per workgroup): set-up 1590, MFMA loop 5140 (35.7 per MFMA), halo write 700,
+// epilogue 1890, barrier 260.  Finishing the previous tile's results INSIDE the next tile's MFMA loop (two accumulator sets, one
+// 4-channel group per step) was built and measured: the loop grows by what the epilogue shrinks (6200 + 2550 of set-up: 9920
+// against 9570 per tile) - a step's four MFMAs leave a lone wave ~50 free issue cycles, a group needs more.  Not kept.
 // One barrier per tile.  The MFMA loop itself (36 steps of 4 ds_read_b128 + 4 MFMAs, fragments requested two steps ahead)
 // runs at 33 cycles per MFMA (tools/mfma_bf16_lds.hip: 34.8 for this mix on its own).
 // =========================================================================================================================
