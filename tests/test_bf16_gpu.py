@@ -57,7 +57,10 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
 
 
-@pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 45, 64, 64), (1, 66, 512, 512)])
+# (the 64-input-channel shapes take the persistent convb64 kernel: 8 x 32 pixel tiles - extents below / at / just above tile
+#  multiples, one to three 64-channel n-blocks, several tiles per workgroup at 9 x 330 tiles)
+@pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 45, 64, 64), (1, 66, 512, 512),
+                                     (2, 10, 64, 64), (1, 34, 64, 64), (1, 35, 64, 192), (3, 7, 64, 64), (9, 330, 64, 64)])
 def test_conv3x3_fwd_bf16(hip, B, H, C, K):
     keep = Keep()
     x = bf(rnd(B, C, H, H, seed=1)); w = bf(rnd(K, C, 3, 3, seed=2, scale=0.05)); b = rnd(K, seed=3).float().double()
@@ -84,8 +87,10 @@ def test_conv3x3_fwd_virtual_concat_bf16(hip, B, Hs, pad, C1, C2, K):
     assert nerr(nchw(y), ref) < TOL_BF16
 
 
+# (dgrad of a K = 64 layer is a 64-input-channel launch with two pixels of virtual zero padding: convb64 with border tiles)
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True), (2, 13, 128, 256, True, True),
-                                                      (1, 70, 64, 64, True, False), (1, 66, 512, 512, True, True), (1, 150, 64, 64, False, False)])
+                                                      (1, 70, 64, 64, True, False), (1, 66, 512, 512, True, True), (1, 150, 64, 64, False, False),
+                                                      (2, 34, 64, 64, True, True), (1, 9, 128, 64, True, False), (5, 200, 64, 64, True, False)])
 def test_conv3x3_bwd_bf16(hip, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = bf(rnd(B, C, H, H, seed=1)).requires_grad_(True)
