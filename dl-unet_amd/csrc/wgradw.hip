@@ -194,71 +194,111 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     const bool last = kg == 3;                      // this lane's tile kg+12 = 15: its neighbour is the extra slot
     const int y_base = WW_PATCH + WW_EXTRA + l15 * 4;
 
-    // V = B^T d B for the tile pair pr (.x tile kg + 8 pr, .y tile +4), column by column
-    auto load_v = [&](int buf, int pr, f32x2 (&v)[16]) {
+    // The loop below is written in CHUNKS separated by scheduling barriers — a few LDS reads, a few packed adds, a few MFMAs —
+    // in the order they are to be issued: left to itself the compiler lumps a transform's 32 packed adds together and waits
+    // for every read right behind its issue, and then a wave feeds the matrix pipe for two thirds of the time only.
+#define WW_SB() __builtin_amdgcn_sched_barrier(0)
+    // raw pixels of column j of the 4x4 patches of tile pair pr (.x tile kg + 8 pr, .y tile +4): 8 ds_read_b32
+    auto v_read = [&](int buf, int pr, int j, f32x2 (&a)[4]) {
         const unsigned char *sb = smem + buf * WW_STAGE;
         const int tA = kg + 8 * pr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x2 a[4];
-#pragma unroll
-            for (int qy = 0; qy < 4; ++qy) {
-                const int row = 2 * qy + (j & 1);
-                if (j < 2) {
-                    const unsigned char *src = sb + a_base + row * 4096 + tA * 64;
-                    a[qy][0] = *(const float *)(src);
+        for (int qy = 0; qy < 4; ++qy) {
+            const int row = 2 * qy + (j & 1);
+            if (j < 2) {
+                const unsigned char *src = sb + a_base + row * 4096 + tA * 64;
+                a[qy][0] = *(const float *)(src);
+                a[qy][1] = *(const float *)(src + 256);
+            } else {
+                const unsigned char *src = sb + a_base + row * 4096 + (tA + 1) * 64;
+                a[qy][0] = *(const float *)(src);
+                if (pr == 0) {
                     a[qy][1] = *(const float *)(src + 256);
                 } else {
-                    const unsigned char *src = sb + a_base + row * 4096 + (tA + 1) * 64;
-                    a[qy][0] = *(const float *)(src);
-                    if (pr == 0) {
-                        a[qy][1] = *(const float *)(src + 256);
-                    } else {
-                        const unsigned char *s2 = last ? sb + e_base + row * 256 : src + 256;
-                        a[qy][1] = *(const float *)(s2);
-                    }
+                    const unsigned char *s2 = last ? sb + e_base + row * 256 : src + 256;
+                    a[qy][1] = *(const float *)(s2);
                 }
             }
-            v[j] = wpk_sub(a[0], a[2]);
-            v[4 + j] = wpk_add(a[1], a[2]);
-            v[8 + j] = wpk_sub(a[2], a[1]);
-            v[12 + j] = wpk_sub(a[1], a[3]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
-            v[4 * i + 0] = wpk_sub(t0, t2);
-            v[4 * i + 1] = wpk_add(t1, t2);
-            v[4 * i + 2] = wpk_sub(t2, t1);
-            v[4 * i + 3] = wpk_sub(t1, t3);
-        }
+        WW_SB();
     };
-    // Z = A dY A^T up to signs (applied in the reduce) for tile pair pr, cj block c; dY = [[a, b], [c, d]] = d[0..3]
-    auto load_z = [&](int buf, int pr, int c, f32x2 (&z)[16]) {
+    // V = B^T d B: column pass of column j (4 packed adds) ...
+    auto v_col = [&](int j, const f32x2 (&a)[4], f32x2 (&v)[16]) {
+        v[j] = wpk_sub(a[0], a[2]);
+        v[4 + j] = wpk_add(a[1], a[2]);
+        v[8 + j] = wpk_sub(a[2], a[1]);
+        v[12 + j] = wpk_sub(a[1], a[3]);
+        WW_SB();
+    };
+    // ... and row pass of row i (4 packed adds)
+    auto v_row = [&](int i, f32x2 (&v)[16]) {
+        const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
+        v[4 * i + 0] = wpk_sub(t0, t2);
+        v[4 * i + 1] = wpk_add(t1, t2);
+        v[4 * i + 2] = wpk_sub(t2, t1);
+        v[4 * i + 3] = wpk_sub(t1, t3);
+        WW_SB();
+    };
+    // dY = [[a, b], [c, d]] = d[0..3] of tile pair pr, cj block c: 8 ds_read_b32
+    auto z_read = [&](int buf, int pr, int c, f32x2 (&d)[4]) {
         const unsigned char *ys = smem + buf * WW_STAGE + y_base + (2 * wj + c) * 1024 + (kg + 8 * pr) * 64;
-        f32x2 d[4];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             d[px][0] = *(const float *)(ys + px * 4096);
             d[px][1] = *(const float *)(ys + px * 4096 + 256);
         }
-        const f32x2 s1 = wpk_add(d[0], d[2]), s2 = wpk_add(d[1], d[3]);
-        const f32x2 s3 = wpk_sub(d[0], d[2]), s4 = wpk_sub(d[1], d[3]);
-        z[0] = d[0];  z[1] = wpk_add(d[0], d[1]); z[2] = wpk_sub(d[0], d[1]); z[3] = d[1];        // sign(3)  = -
-        z[4] = s1;    z[5] = wpk_add(s1, s2);     z[6] = wpk_sub(s1, s2);     z[7] = s2;          // sign(7)  = -
-        z[8] = s3;    z[9] = wpk_add(s3, s4);     z[10] = wpk_sub(s3, s4);    z[11] = s4;         // sign(11) = -
-        z[12] = d[2]; z[13] = wpk_add(d[2], d[3]); z[14] = wpk_sub(d[2], d[3]); z[15] = d[3];     // sign(12,13,14) = -
-        dbacc[c] = wpk_add(dbacc[c], wpk_add(z[1], z[13]));
+        WW_SB();
     };
-    auto mfma32 = [&](const f32x2 (&v)[16], const f32x2 (&z)[16], int c) {
+    // One GROUP = the 32 MFMAs of (tile pair, cj block): V[xi] (registers, transformed) x Z[xi], where Z = A dY A^T up to signs
+    // (applied in the reduce) is NOT kept as a 16-entry set: a lane holds the raw dY = [[d0, d1], [d2, d3]] (8 registers) and forms
+    // the four Z[xi] of a block of xi right in front of their MFMAs (12 packed adds per group) — 24 registers less per operand
+    // set, which is what lets the next V transform and the next dY reads ride in the shadow of the group without spilling.
+    // MFMA order inside a block: xi 4b..4b+3 for tile half 0, then for half 1 (dependent accumulations four MFMAs apart).
+    // mode 0: plain group; +1: read dn <- dY(bufz, prz, cz) under it; +2: also transform V(bufv, prv) into vn under it.
+    auto group = [&](const f32x2 (&v)[16], const f32x2 (&d)[4], int c, int mode, int bufz, int prz, int cz, f32x2 (&dn)[4],
+                     int bufv, int prv, f32x2 (&vn)[16]) {
+        const bool DZ = mode & 1, DV = mode & 2;
+        f32x2 a0[4], a1[4], zt[4];
+        auto quad = [&](int b, int h) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int x = 0; x < 16; ++x)
-                acc[x][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x][h], z[x][h], acc[x][c], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+                acc[4 * b + e][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * b + e][h], zt[e][h], acc[4 * b + e][c], 0, 0, 0);
+            WW_SB();
+        };
+        // block 0: Z0..3 = d0, d0+d1, d0-d1, d1 (sign(3) = -)
+        zt[0] = d[0]; zt[1] = wpk_add(d[0], d[1]); zt[2] = wpk_sub(d[0], d[1]); zt[3] = d[1];
+        WW_SB();
+        quad(0, 0);
+        if (DV) v_read(bufv, prv, 0, a0);
+        else if (DZ) z_read(bufz, prz, cz, dn);
+        quad(0, 1);
+        if (DV) v_read(bufv, prv, 1, a1);
+        // block 1: Z4..7 = s1, s1+s2, s1-s2, s2 with s1 = d0+d2, s2 = d1+d3 (sign(7) = -)
+        zt[0] = wpk_add(d[0], d[2]); zt[3] = wpk_add(d[1], d[3]); zt[1] = wpk_add(zt[0], zt[3]); zt[2] = wpk_sub(zt[0], zt[3]);
+        WW_SB();
+        quad(1, 0);
+        if (DV) { v_col(0, a0, vn); v_read(bufv, prv, 2, a0); }
+        quad(1, 1);
+        if (DV) { v_col(1, a1, vn); v_read(bufv, prv, 3, a1); }
+        // block 2: Z8..11 = s3, s3+s4, s3-s4, s4 with s3 = d0-d2, s4 = d1-d3 (sign(11) = -)
+        zt[0] = wpk_sub(d[0], d[2]); zt[3] = wpk_sub(d[1], d[3]); zt[1] = wpk_add(zt[0], zt[3]); zt[2] = wpk_sub(zt[0], zt[3]);
+        WW_SB();
+        quad(2, 0);
+        if (DV) v_col(2, a0, vn);
+        quad(2, 1);
+        if (DV) { v_col(3, a1, vn); v_row(0, vn); }
+        // block 3: Z12..15 = d2, d2+d3, d2-d3, d3 (sign(12,13,14) = -); the bias partial (sum of the four dY) rides here
+        zt[0] = d[2]; zt[1] = wpk_add(d[2], d[3]); zt[2] = wpk_sub(d[2], d[3]); zt[3] = d[3];
+        dbacc[c] = wpk_add(dbacc[c], wpk_add(wpk_add(d[0], d[1]), zt[1]));
+        WW_SB();
+        quad(3, 0);
+        if (DV) { v_row(1, vn); v_row(2, vn); }
+        if (DV && DZ) z_read(bufz, prz, cz, dn);
+        quad(3, 1);
+        if (DV) v_row(3, vn);
     };
-    // ---- pipeline: stage s+2 is issued at the start of step s (into the buffer step s-1 freed); at the end of step s
-    // everything but that batch has landed -> stage s+1.
+    // ---- pipeline: stage s+2 is issued during step s (into the buffer step s-1 freed); at the barrier of step s everything
+    // but that batch has landed -> stage s+1.
     if (ns > 0) {
         stage(0, s0);
         if (ns > 1) stage(1, s0 + 1);
@@ -267,36 +307,41 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
         // the two waves of a SIMD (w, w+4) issue their LDS-DMA batch half a step apart: one wave's ~200-cycle-per-
         // instruction issue then overlaps the partner's MFMAs
         const bool early = wave < 4;
+        // software pipeline across the steps: the operands of a group are read and transformed in the shadow of the previous
+        // group (each MFMA leaves 24 of its 32 cycles of vector issue free) — including the first group of step s+1, whose
+        // stage has landed by the time the last group of step s starts: the barrier sits in front of that group, not after it.
+        f32x2 va[16], vb[16], da[4], db_[4];
+        {
+            f32x2 a0[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v_read(0, 0, j, a0); v_col(j, a0, va); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v_row(i, va);
+        }
+        z_read(0, 0, 0, da);
+        if (ns > 2 && early) stage(2, s0 + 2);
+        WW_SB();
         for (int s = 0; s < ns; ++s) {
             const bool more = s + 2 < ns;
-            const int buf = s % WW_NST;
-            if (more && early) stage((s + 2) % WW_NST, s0 + s + 2);
-            {
-                // software pipeline inside the step: the operands of the next 32 MFMAs are read and transformed in the
-                // shadow of the current 32 (each MFMA leaves 24 of its 32 cycles of vector issue free)
-                f32x2 va[16], vb[16], za[16], zb[16];
-                load_v(buf, 0, va);
-                load_z(buf, 0, 0, za);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma32(va, za, 0);
-                load_z(buf, 0, 1, zb);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma32(va, zb, 1);
-                load_v(buf, 1, vb);
-                __builtin_amdgcn_sched_barrier(0);
-                load_z(buf, 1, 0, za);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma32(vb, za, 0);
-                load_z(buf, 1, 1, zb);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma32(vb, zb, 1);
-            }
+            const int buf = s % WW_NST, nbuf = (s + 1) % WW_NST;
+            WW_SB();
+            group(va, da, 0, 1, buf, 0, 1, db_, 0, 0, vb);                    // (pair 0, c 0); reads dY(pair 0, c 1)
+            group(va, db_, 1, 3, buf, 1, 0, da, buf, 1, vb);                  // (pair 0, c 1); V(pair 1), dY(pair 1, c 0)
+            if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
+            WW_SB();
+            group(vb, da, 0, 1, buf, 1, 1, db_, 0, 0, va);                    // (pair 1, c 0); reads dY(pair 1, c 1)
+            // every read of this step's buffer has returned (the buffer is refilled by a stage issued after this barrier) and
+            // stage s+1 has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_landed(more);
             __builtin_amdgcn_s_barrier();
+            WW_SB();
+            group(vb, db_, 1, 3, nbuf, 0, 0, da, nbuf, 0, va);                // (pair 1, c 1); next step's V(pair 0), dY(pair 0, c 0)
+            if (s + 3 < ns && early) stage(buf, s0 + s + 3);                  // (past the last step: stale LDS, never used)
+            WW_SB();
         }
     }
+#undef WW_SB
 
     // ---- slab: [xi 16][cj 64][ci 64] | db[64].  D lane layout: ci = 4*kg + r, cj = l15: ci is the fast index, so the four
     // accumulator registers of a (xi, c) are one 16-byte store (32 store instructions per lane instead of 128 dword stores) and

@@ -6,7 +6,7 @@ ARGS=$1; shift
 mkdir -p $OUT
 i=0
 for E in "$@"; do
-  tag=$(echo "$E" | tr ' =' '__')
+  tag=$(echo "$E" | tr ' =/' '___')
   env $E python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 $ARGS --detail $OUT/detail_$tag.json > $OUT/line_$tag.json 2> $OUT/err_$tag.txt
   python3 - "$OUT/line_$tag.json" "$E" <<'PY'
 import json, sys
