@@ -45,6 +45,9 @@ struct WgradWK {
     int xbytes, ybytes;       // buffer-descriptor sizes of X and Y (bytes); the buffer path needs both below 2 GiB
 };
 
+#ifndef WW_DBG
+#define WW_DBG 0
+#endif
 constexpr int WW_PATCH = 32768, WW_EXTRA = 2048, WW_DY = 16384;
 constexpr int WW_STAGE = WW_PATCH + WW_EXTRA + WW_DY;       // 51200
 constexpr int WW_NST = 3;
@@ -199,31 +202,35 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     // for every read right behind its issue, and then a wave feeds the matrix pipe for two thirds of the time only.
 #define WW_SB() __builtin_amdgcn_sched_barrier(0)
     // raw pixels of column j of the 4x4 patches of tile pair pr (.x tile kg + 8 pr, .y tile +4): 8 ds_read_b32
+    // (addresses: one per-lane base per call + compile-time offsets that fit the instructions' offset fields; the extra slot of
+    // the lanes with kg = 3 through a per-lane base and row stride instead of a select per read)
+    const int lv = a_base + kg * 64;
+    const int lx = last ? e_base : lv + 9 * 64 + 256;       // pair 1, columns 2,3, .y: tile kg + 13 or the extra slot
+    const int lxs = last ? 512 : 8192;                      // ... and its stride per qy (two rows)
+    const int ly = y_base + 2 * wj * 1024 + kg * 64;
     auto v_read = [&](int buf, int pr, int j, f32x2 (&a)[4]) {
-        const unsigned char *sb = smem + buf * WW_STAGE;
-        const int tA = kg + 8 * pr;
+        if (WW_DBG & 4) { WW_SB(); return; }
+        const unsigned char *pv = smem + buf * WW_STAGE + lv;
+        if (j < 2 || pr == 0) {
 #pragma unroll
-        for (int qy = 0; qy < 4; ++qy) {
-            const int row = 2 * qy + (j & 1);
-            if (j < 2) {
-                const unsigned char *src = sb + a_base + row * 4096 + tA * 64;
+            for (int qy = 0; qy < 4; ++qy) {
+                const unsigned char *src = pv + ((2 * qy + (j & 1)) * 4096 + (8 * pr + (j >> 1)) * 64);
                 a[qy][0] = *(const float *)(src);
                 a[qy][1] = *(const float *)(src + 256);
-            } else {
-                const unsigned char *src = sb + a_base + row * 4096 + (tA + 1) * 64;
-                a[qy][0] = *(const float *)(src);
-                if (pr == 0) {
-                    a[qy][1] = *(const float *)(src + 256);
-                } else {
-                    const unsigned char *s2 = last ? sb + e_base + row * 256 : src + 256;
-                    a[qy][1] = *(const float *)(s2);
-                }
+            }
+        } else {
+            const unsigned char *px = smem + buf * WW_STAGE + lx + (j & 1) * (lxs >> 1);
+#pragma unroll
+            for (int qy = 0; qy < 4; ++qy) {
+                a[qy][0] = *(const float *)(pv + ((2 * qy + (j & 1)) * 4096 + 9 * 64));
+                a[qy][1] = *(const float *)(px + qy * lxs);
             }
         }
         WW_SB();
     };
     // V = B^T d B: column pass of column j (4 packed adds) ...
     auto v_col = [&](int j, const f32x2 (&a)[4], f32x2 (&v)[16]) {
+        if (WW_DBG & 8) { WW_SB(); return; }
         v[j] = wpk_sub(a[0], a[2]);
         v[4 + j] = wpk_add(a[1], a[2]);
         v[8 + j] = wpk_sub(a[2], a[1]);
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     };
     // ... and row pass of row i (4 packed adds)
     auto v_row = [&](int i, f32x2 (&v)[16]) {
+        if (WW_DBG & 8) { WW_SB(); return; }
         const f32x2 t0 = v[4 * i], t1 = v[4 * i + 1], t2 = v[4 * i + 2], t3 = v[4 * i + 3];
         v[4 * i + 0] = wpk_sub(t0, t2);
         v[4 * i + 1] = wpk_add(t1, t2);
@@ -241,24 +249,26 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     };
     // dY = [[a, b], [c, d]] = d[0..3] of tile pair pr, cj block c: 8 ds_read_b32
     auto z_read = [&](int buf, int pr, int c, f32x2 (&d)[4]) {
-        const unsigned char *ys = smem + buf * WW_STAGE + y_base + (2 * wj + c) * 1024 + (kg + 8 * pr) * 64;
+        if (WW_DBG & 4) { WW_SB(); return; }
+        const unsigned char *ys = smem + buf * WW_STAGE + ly;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            d[px][0] = *(const float *)(ys + px * 4096);
-            d[px][1] = *(const float *)(ys + px * 4096 + 256);
+            d[px][0] = *(const float *)(ys + (px * 4096 + c * 1024 + pr * 512));
+            d[px][1] = *(const float *)(ys + (px * 4096 + c * 1024 + pr * 512 + 256));
         }
         WW_SB();
     };
     // One GROUP = the 32 MFMAs of (tile pair, cj block): V[xi] (registers, transformed) x Z[xi], where Z = A dY A^T up to signs
     // (applied in the reduce) is NOT kept as a 16-entry set: a lane holds the raw dY = [[d0, d1], [d2, d3]] (8 registers) and forms
     // the four Z[xi] of a block of xi right in front of their MFMAs (12 packed adds per group) — 24 registers less per operand
-    // set, which is what lets the next V transform and the next dY reads ride in the shadow of the group without spilling.
+    // set, which is what lets the next operands' reads and transform ride in the shadow of the groups without spilling.
     // MFMA order inside a block: xi 4b..4b+3 for tile half 0, then for half 1 (dependent accumulations four MFMAs apart).
-    // mode 0: plain group; +1: read dn <- dY(bufz, prz, cz) under it; +2: also transform V(bufv, prv) into vn under it.
-    auto group = [&](const f32x2 (&v)[16], const f32x2 (&d)[4], int c, int mode, int bufz, int prz, int cz, f32x2 (&dn)[4],
-                     int bufv, int prv, f32x2 (&vn)[16]) {
-        const bool DZ = mode & 1, DV = mode & 2;
-        f32x2 a0[4], a1[4], zt[4];
+    // Under every group: dn <- raw dY(bufz, prz, cz), the NEXT group's.  RD: also the 32 raw patch reads of V(bufv, prv) into r
+    // (used a whole group later: the CU's eight waves run in step and send their reads at the same moments, so a read takes
+    // several hundred cycles to come back); XF: transform r into vn.
+    auto group = [&](const f32x2 (&v)[16], const f32x2 (&d)[4], int c, bool RD, bool XF, int bufz, int prz, int cz, f32x2 (&dn)[4],
+                     int bufv, int prv, f32x2 (&r)[4][4], f32x2 (&vn)[16]) {
+        f32x2 zt[4];
         auto quad = [&](int b, int h) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -269,75 +279,75 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
         zt[0] = d[0]; zt[1] = wpk_add(d[0], d[1]); zt[2] = wpk_sub(d[0], d[1]); zt[3] = d[1];
         WW_SB();
         quad(0, 0);
-        if (DV) v_read(bufv, prv, 0, a0);
-        else if (DZ) z_read(bufz, prz, cz, dn);
+        z_read(bufz, prz, cz, dn);
         quad(0, 1);
-        if (DV) v_read(bufv, prv, 1, a1);
+        if (RD) v_read(bufv, prv, 0, r[0]);
+        if (XF) { v_col(0, r[0], vn); v_col(1, r[1], vn); }
         // block 1: Z4..7 = s1, s1+s2, s1-s2, s2 with s1 = d0+d2, s2 = d1+d3 (sign(7) = -)
         zt[0] = wpk_add(d[0], d[2]); zt[3] = wpk_add(d[1], d[3]); zt[1] = wpk_add(zt[0], zt[3]); zt[2] = wpk_sub(zt[0], zt[3]);
         WW_SB();
         quad(1, 0);
-        if (DV) { v_col(0, a0, vn); v_read(bufv, prv, 2, a0); }
+        if (RD) v_read(bufv, prv, 1, r[1]);
+        if (XF) { v_col(2, r[2], vn); v_col(3, r[3], vn); }
         quad(1, 1);
-        if (DV) { v_col(1, a1, vn); v_read(bufv, prv, 3, a1); }
+        if (RD) v_read(bufv, prv, 2, r[2]);
+        if (XF) v_row(0, vn);
         // block 2: Z8..11 = s3, s3+s4, s3-s4, s4 with s3 = d0-d2, s4 = d1-d3 (sign(11) = -)
         zt[0] = wpk_sub(d[0], d[2]); zt[3] = wpk_sub(d[1], d[3]); zt[1] = wpk_add(zt[0], zt[3]); zt[2] = wpk_sub(zt[0], zt[3]);
         WW_SB();
         quad(2, 0);
-        if (DV) v_col(2, a0, vn);
+        if (RD) v_read(bufv, prv, 3, r[3]);
+        if (XF) v_row(1, vn);
         quad(2, 1);
-        if (DV) { v_col(3, a1, vn); v_row(0, vn); }
+        if (XF) v_row(2, vn);
         // block 3: Z12..15 = d2, d2+d3, d2-d3, d3 (sign(12,13,14) = -); the bias partial (sum of the four dY) rides here
         zt[0] = d[2]; zt[1] = wpk_add(d[2], d[3]); zt[2] = wpk_sub(d[2], d[3]); zt[3] = d[3];
         dbacc[c] = wpk_add(dbacc[c], wpk_add(wpk_add(d[0], d[1]), zt[1]));
         WW_SB();
         quad(3, 0);
-        if (DV) { v_row(1, vn); v_row(2, vn); }
-        if (DV && DZ) z_read(bufz, prz, cz, dn);
+        if (XF) {
+            v_row(3, vn);
+            // pin the transform here: without a use in this block the compiler sinks the packed adds towards their use
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(vn[i]));
+        }
         quad(3, 1);
-        if (DV) v_row(3, vn);
     };
-    // ---- pipeline: stage s+2 is issued during step s (into the buffer step s-1 freed); at the barrier of step s everything
-    // but that batch has landed -> stage s+1.
+    // ---- pipeline over a 3-deep ring.  Step s = four groups on buffer s%3; the barrier B_s sits in its middle: behind it stage
+    // s+1 is visible to everybody (groups 3, 4 already read the next step's first operands from it) and every wave has left
+    // step s-1, whose buffer stage s+2 refills — issued right after B_s by the waves 0-3 and at the end of the step by the waves
+    // 4-7 (the two waves of a SIMD, w and w+4, issue their LDS-DMA batch half a step apart: one wave's ~200 cycles per
+    // instruction then overlap the partner's MFMAs); either way it has until B_(s+1) to land.
     if (ns > 0) {
         stage(0, s0);
         if (ns > 1) stage(1, s0 + 1);
         wait_landed(ns > 1);
         __builtin_amdgcn_s_barrier();
-        // the two waves of a SIMD (w, w+4) issue their LDS-DMA batch half a step apart: one wave's ~200-cycle-per-
-        // instruction issue then overlaps the partner's MFMAs
         const bool early = wave < 4;
-        // software pipeline across the steps: the operands of a group are read and transformed in the shadow of the previous
-        // group (each MFMA leaves 24 of its 32 cycles of vector issue free) — including the first group of step s+1, whose
-        // stage has landed by the time the last group of step s starts: the barrier sits in front of that group, not after it.
-        f32x2 va[16], vb[16], da[4], db_[4];
+        f32x2 va[16], vb[16], da[4], db_[4], r[4][4];
         {
-            f32x2 a0[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v_read(0, 0, j, a0); v_col(j, a0, va); }
+            for (int j = 0; j < 4; ++j) { v_read(0, 0, j, r[j]); v_col(j, r[j], va); }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v_row(i, va);
         }
         z_read(0, 0, 0, da);
-        if (ns > 2 && early) stage(2, s0 + 2);
-        WW_SB();
         for (int s = 0; s < ns; ++s) {
             const bool more = s + 2 < ns;
             const int buf = s % WW_NST, nbuf = (s + 1) % WW_NST;
             WW_SB();
-            group(va, da, 0, 1, buf, 0, 1, db_, 0, 0, vb);                    // (pair 0, c 0); reads dY(pair 0, c 1)
-            group(va, db_, 1, 3, buf, 1, 0, da, buf, 1, vb);                  // (pair 0, c 1); V(pair 1), dY(pair 1, c 0)
-            if (more && !early) stage((s + 2) % WW_NST, s0 + s + 2);
+            group(va, da, 0, true, false, buf, 0, 1, db_, buf, 1, r, vb);       // (pair 0, c 0); reads dY(pair 0, c 1), raw V(pair 1)
+            group(va, db_, 1, false, true, buf, 1, 0, da, buf, 1, r, vb);       // (pair 0, c 1); V(pair 1); reads dY(pair 1, c 0)
+            // stage s+1 has landed (nothing newer is in flight) and every wave is past step s-1
+            if (!(WW_DBG & 1)) ww_wait_vmcnt<0>();
+            if (!(WW_DBG & 2)) __builtin_amdgcn_s_barrier();
             WW_SB();
-            group(vb, da, 0, 1, buf, 1, 1, db_, 0, 0, va);                    // (pair 1, c 0); reads dY(pair 1, c 1)
-            // every read of this step's buffer has returned (the buffer is refilled by a stage issued after this barrier) and
-            // stage s+1 has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_landed(more);
-            __builtin_amdgcn_s_barrier();
+            if (more && early && !(WW_DBG & 1)) stage((s + 2) % WW_NST, s0 + s + 2);
             WW_SB();
-            group(vb, db_, 1, 3, nbuf, 0, 0, da, nbuf, 0, va);                // (pair 1, c 1); next step's V(pair 0), dY(pair 0, c 0)
-            if (s + 3 < ns && early) stage(buf, s0 + s + 3);                  // (past the last step: stale LDS, never used)
+            // (past the last step these read stale LDS that nobody uses)
+            group(vb, da, 0, true, false, buf, 1, 1, db_, nbuf, 0, r, va);      // (pair 1, c 0); reads dY(pair 1, c 1), next raw V(pair 0)
+            group(vb, db_, 1, false, true, nbuf, 0, 0, da, nbuf, 0, r, va);     // (pair 1, c 1); next V(pair 0); reads next dY(pair 0, c 0)
+            if (more && !early && !(WW_DBG & 1)) stage((s + 2) % WW_NST, s0 + s + 2);
             WW_SB();
         }
     }
