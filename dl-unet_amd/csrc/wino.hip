@@ -150,6 +150,15 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     const int l15 = lane & 15, kg = lane >> 4;
     const int tpi = k.tiles_x * k.tiles_y;
     const int ns = k.nsteps;
+    // the epilogue's kernel arguments, fetched now in one batch and pinned in SGPRs: fetched where they are used, each costs the
+    // epilogue a scalar-load round trip behind a branch (fourteen of them in a row)
+    int e_scatter = p.scatter, e_DH = p.DH, e_DW = p.DW, e_DC = p.DC, e_dwy0 = p.dwy0, e_dwx0 = p.dwx0, e_OH = p.OH, e_OW = p.OW;
+    int e_rw0 = p.rw0, e_rw1 = p.rw1, e_dn0 = p.dn0, e_cout = p.cout, e_relu = p.relu, e_Nn = p.Nn, e_MT = k.MT;
+    const float *e_add = p.add, *e_mask = p.mask, *e_bias = p.bias;
+    float *e_dst = p.dst, *e_pool = p.pool_dst;
+    asm volatile("" : "+s"(e_scatter), "+s"(e_DH), "+s"(e_DW), "+s"(e_DC), "+s"(e_dwy0), "+s"(e_dwx0), "+s"(e_OH), "+s"(e_OW));
+    asm volatile("" : "+s"(e_rw0), "+s"(e_rw1), "+s"(e_dn0), "+s"(e_cout), "+s"(e_relu), "+s"(e_Nn), "+s"(e_MT));
+    asm volatile("" : "+s"(e_add), "+s"(e_mask), "+s"(e_bias), "+s"(e_dst), "+s"(e_pool));
 
     int slot;
     {
@@ -166,7 +175,6 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         nt = (ng << k.gn_shift) + (rem & (k.gn - 1));
     }
     const int T0 = mt * 64, n0 = nt * 32;
-    const int R0 = fdiv(T0, k.d_tx);
 
     // U: the 32 channels are half (nt & 1) of the 64-channel block nt >> 1
     const float *ublk = k.U + (size_t)(nt >> 1) * ns * 8192 + (nt & 1) * 4096 + (4 * wave) * 256 + lane * 4;
@@ -194,43 +202,64 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         ++uissued;
     };
     // ---- DMA role: patch instructions i = wave + 4*ii (i < 18): 5 for waves 0,1, 4 for waves 2,3; U pieces 4*wave .. +3
+    // The per-lane source offsets are worked out branch-free from kernel arguments read up front in one batch: written with
+    // the conditions as branches, the compiler fetches each argument under the condition that needs it — thirty dependent
+    // scalar-load round trips, 4-7k cycles per workgroup (in-kernel stamps).
     constexpr int NPI = 5;
     const int npi = wave < 2 ? 5 : 4;
     int poff[NPI];
     int *poff1 = (int *)(smem + W32_LDS + 1280) + tid;
+    // tile T0 (uniform: scalar unit) -> image, tile row, tile column; a lane's tile is at most 63 tiles, 7 tile rows and (at least 7
+    // tile rows per image: wino_applicable) one image further.  x / tiles_x by an exact float floor (values below 2^12).
+    const int tiles_x = k.tiles_x;
+    const int img0 = fdiv(T0, k.d_tpi);
+    const int trem0 = T0 - img0 * tpi;
+    const int ty0 = fdiv(trem0, k.d_tx);
+    const int tx0 = trem0 - ty0 * tiles_x;
+    const float rtx = 1.0f / (float)tiles_x;
+    {
+        const int nsrc = p.nsrc, oy0 = p.oy0, ox0 = p.ox0, MT = k.MT;
+        const int img0_ = img0;
+        int sH[2], sW[2], sC[2], sc0[2], spad[2];
 #pragma unroll
-    for (int ii = 0; ii < NPI; ++ii) {
-        const int pos = (wave + 4 * ii) * 1024 + lane * 16;
-        const int row = pos / WINO_ROW;
-        const int rem = pos - row * WINO_ROW;
-        const int idx = rem >> 5;
-        const int qy = row >> 1, par = row & 1, half = ((rem >> 4) & 1) ^ ((idx >> 3) & 1);
-        int T, qx;
-        bool ok = true;
-        if (idx < 64) {
-            T = T0 + idx; qx = par;
-        } else {
+        for (int si = 0; si < 2; ++si) { sH[si] = p.src[si].H; sW[si] = p.src[si].W; sC[si] = p.src[si].C; sc0[si] = p.src[si].c0; spad[si] = p.src[si].pad; }
+        // offset = image base (one of two scalars) + row * row pitch + column * channels: 24-bit multiplies (full rate; rows,
+        // columns and channels are below 2^12, a row pitch below 2^24)
+        int rowp[2], imgb[2][2];
+#pragma unroll
+        for (int si = 0; si < 2; ++si) { rowp[si] = sW[si] * sC[si]; imgb[si][0] = img0_ * sH[si] * rowp[si] + sc0[si]; imgb[si][1] = imgb[si][0] + sH[si] * rowp[si]; }
+        const int lastrel = MT - 1 - T0;
+#pragma unroll
+        for (int ii = 0; ii < NPI; ++ii) {
+            // byte position in the stage, in 16-byte units: u = row * 144 + idx * 2 + slot  (exact float floor: u < 1152)
+            const int u = (wave + 4 * ii) * 64 + lane;
+            const int row = (int)(((float)u + 0.5f) * (1.0f / 144.0f));
+            const int rem = u - row * 144;
+            const int idx = rem >> 1;
+            const int qy = row >> 1, par = row & 1, half = (rem & 1) ^ ((idx >> 3) & 1);
+            // tile index relative to T0: own tiles 0..63; tail j: the last tile of tile row R0 + j, or tile 63
+            const bool tail = idx >= 64;
             const int j = idx - 64;
-            ok = (R0 + j) * k.tiles_x <= T0 + 63;
-            T = (R0 + j + 1) * k.tiles_x - 1;
-            T = T < T0 + 63 ? T : T0 + 63;
-            qx = 2 + par;
-        }
-        T = T < k.MT ? T : k.MT - 1;
-        const int img = fdiv(T, k.d_tpi);
-        const int trem = T - img * tpi;
-        const int ty = fdiv(trem, k.d_tx);
-        const int tx = trem - ty * k.tiles_x;
+            const int erow = j * tiles_x - tx0;                       // first tile of row R0 + j, relative
+            int e = tail ? erow + tiles_x - 1 : idx;
+            e = e < 63 ? e : 63;
+            e = e < lastrel ? e : lastrel;
+            const bool ok = !tail | (erow <= 63);
+            const int qx = tail ? 2 + par : par;
+            const int t = tx0 + e;
+            const int r = (int)(((float)t + 0.5f) * rtx);
+            const int tx = t - r * tiles_x;
+            int ty = ty0 + r;
+            const bool wrap = ty >= k.tiles_y;
+            ty = wrap ? ty - k.tiles_y : ty;
 #pragma unroll
-        for (int si = 0; si < 2; ++si) {
-            int o = -1;
-            if (si < p.nsrc && ii < npi) {
-                const GSrc &g = p.src[si];
-                const int iy = 2 * ty + p.oy0 - g.pad + qy, ix = 2 * tx + p.ox0 - g.pad + qx;
-                const bool inb = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                o = inb ? ((img * g.H + iy) * g.W + ix) * g.C + g.c0 + 4 * half : -1;
+            for (int si = 0; si < 2; ++si) {
+                const int iy = 2 * ty + oy0 - spad[si] + qy, ix = 2 * tx + ox0 - spad[si] + qx;
+                const bool inb = ok & ((unsigned)iy < (unsigned)sH[si]) & ((unsigned)ix < (unsigned)sW[si]) & (si < nsrc) & (ii < npi);
+                int o = (wrap ? imgb[si][1] : imgb[si][0]) + __mul24(iy, rowp[si]) + __mul24(ix, sC[si]) + 4 * half;
+                o = inb ? o : -1;
+                if (si == 0) poff[ii] = o; else if (nsrc > 1) poff1[ii * 256] = o;
             }
-            if (si == 0) poff[ii] = o; else if (p.nsrc > 1) poff1[ii * 256] = o;
         }
     }
     const float *sp = p.src[0].p;
@@ -243,10 +272,10 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     const int offA = tl * 32 + (((kg >> 1) ^ ((tl >> 3) & 1)) * 16) + (kg & 1) * 8;
     int offB;
     {
-        const int T = T0 + tl;
-        const int R = fdiv(T, k.d_tx);
-        const bool rowend = (T - R * k.tiles_x == k.tiles_x - 1) || tl == 63;
-        int j = R - R0;
+        const int t = tx0 + tl;
+        const int r = (int)(((float)t + 0.5f) * rtx);
+        const bool rowend = (t - r * tiles_x == tiles_x - 1) || tl == 63;
+        int j = r;                                                         // tile row of the lane's tile - tile row of T0
         j = j < 7 ? j : 7;
         const int idxB = rowend ? 64 + j : tl + 1;
         offB = idxB * 32 + (((kg >> 1) ^ ((idxB >> 3) & 1)) * 16) + (kg & 1) * 8;
@@ -362,28 +391,33 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     unsigned char *rflag = smem + W32_LDS + 1024;
     {
         const int tl2 = tid >> 2, py = (tid >> 1) & 1, px = tid & 1;
-        int T = T0 + tl2;
-        const bool tok = T < k.MT;
-        T = tok ? T : k.MT - 1;
-        const int img = fdiv(T, k.d_tpi);
-        const int rem = T - img * tpi;
-        const int ty = fdiv(rem, k.d_tx);
-        const int tx = rem - ty * k.tiles_x;
+        const int lastrel = e_MT - 1 - T0;
+        const bool tok = tl2 <= lastrel;
+        // tile T0 + tl2 -> (image, tile row, tile column) as in the set-up: float floor, one image wrap
+        const int t = tx0 + (tok ? tl2 : lastrel);
+        const int r = (int)(((float)t + 0.5f) * rtx);
+        const int tx = t - r * tiles_x;
+        int ty = ty0 + r;
+        const bool wrap = ty >= k.tiles_y;
+        ty = wrap ? ty - k.tiles_y : ty;
         int oy = 2 * ty + py, ox = 2 * tx + px;
-        const bool ok = tok && oy < p.OH && ox < p.OW;
-        oy = oy < p.OH ? oy : p.OH - 1; ox = ox < p.OW ? ox : p.OW - 1;
-        unsigned off;
-        if (p.scatter == 2) off = (unsigned)((img * p.DH + oy + p.dwy0) * p.DW + ox + p.dwx0) * (unsigned)p.DC;
-        else off = (unsigned)((img * p.OH + oy) * p.OW + ox) * (unsigned)p.DC;
+        const bool ok = tok & (oy < e_OH) & (ox < e_OW);
+        oy = oy < e_OH ? oy : e_OH - 1; ox = ox < e_OW ? ox : e_OW - 1;
+        // destination pixel: window scatter (2) or dst pixel == output pixel; rows, columns, channels below 2^12: 24-bit multiplies
+        const bool win = e_scatter == 2;
+        const int PH = win ? e_DH : e_OH, PW = win ? e_DW : e_OW, py0 = win ? e_dwy0 : 0, px0 = win ? e_dwx0 : 0;
+        const int rowp = PW * e_DC;
+        const int ib = (img0 + (wrap ? 1 : 0)) * PH * rowp;                  // (two scalar values)
+        const unsigned off = (unsigned)(ib + __mul24(oy + py0, rowp) + __mul24(ox + px0, e_DC));
         rowoff[tid] = off;
-        const bool inwin = (p.rw1 > p.rw0) && oy >= p.rw0 && oy < p.rw1 && ox >= p.rw0 && ox < p.rw1;
+        const bool inwin = (e_rw1 > e_rw0) & (oy >= e_rw0) & (oy < e_rw1) & (ox >= e_rw0) & (ox < e_rw1);
         rflag[tid] = (ok ? 0 : 1) | (inwin ? 2 : 0);
     }
     __syncthreads();                 // K loop done in every wave (the staging aliases the U ring); row tables visible
 
     // destination offsets of this thread's 2 x 4 rows, and the +add / ReLU' mask operands: issued now, their latency runs
     // under the output transform
-    const bool relu_win = p.rw1 > p.rw0;
+    const bool relu_win = e_rw1 > e_rw0;
     const int c4 = tid & 7;
     const int ncol = n0 + 4 * c4;
     size_t eo[2][4];
@@ -394,20 +428,20 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = (h * 32 + (tid >> 3)) * 4 + u;                 // the four pixels of one tile
-            eo[h][u] = (size_t)rowoff[row] + (size_t)(p.dn0 + ncol);
+            eo[h][u] = (size_t)rowoff[row] + (size_t)(e_dn0 + ncol);
             efl[h][u] = rflag[row];
         }
-    if (p.add) {
+    if (e_add) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) eadd[h][u] = *(const f32x4 *)(p.add + eo[h][u]);
+            for (int u = 0; u < 4; ++u) eadd[h][u] = *(const f32x4 *)(e_add + eo[h][u]);
     }
-    if (p.mask) {
+    if (e_mask) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) emask[h][u] = *(const f32x4 *)(p.mask + eo[h][u]);
+            for (int u = 0; u < 4; ++u) emask[h][u] = *(const f32x4 *)(e_mask + eo[h][u]);
     }
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
@@ -434,9 +468,9 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
     }
     __syncthreads();
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    if (e_bias) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = p.bias[p.cout ? n % p.cout : n]; }
+        for (int c = 0; c < 4; ++c) { const int n = ncol + c; bv[c] = e_bias[e_cout ? n % e_cout : n]; }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -445,11 +479,11 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             v[u] = *(const f32x4 *)(stg + tloc * 128 + (u ^ (tloc & 1)) * 32 + ((4 * c4) ^ (((tloc >> 2) & 1) << 4))) + bv;
-        if (p.add) {
+        if (e_add) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] += eadd[h][u];
         }
-        if (p.relu) {
+        if (e_relu) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool defer = relu_win && (efl[h][u] & 2);
@@ -457,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
                 for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] > 0.f || defer) ? v[u][c] : 0.f;
             }
         }
-        if (p.mask) {
+        if (e_mask) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -465,16 +499,16 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (!(efl[h][u] & 1)) *(f32x4 *)(p.dst + eo[h][u]) = v[u];
-        if (p.pool_dst) {
+            if (!(efl[h][u] & 1)) *(f32x4 *)(e_dst + eo[h][u]) = v[u];
+        if (e_pool) {
             // fused 2x2 max-pool (network.py:132-150): a Winograd tile IS one pooling window and the linear tile index
             // is the pooled pixel index (launch_wino checks even extents)
             const int T = T0 + tloc;
-            if (T < k.MT) {
+            if (T < e_MT) {
                 f32x4 m;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaxf(v[0][c], v[1][c]), fmaxf(v[2][c], v[3][c]));
-                *(f32x4 *)(p.pool_dst + (size_t)T * p.Nn + ncol) = m;
+                *(f32x4 *)(e_pool + (size_t)T * e_Nn + ncol) = m;
             }
         }
     }
@@ -486,6 +520,7 @@ bool wino_applicable(const IgemmP &p)
     if (p.T != 9 || p.TX != 3 || p.stride != 1 || p.scatter == 1) return false;
     if (p.Nn % 64 != 0) return false;
     if (cdiv(p.OW, 2) < 9) return false;      // a workgroup's 64 linear tiles may then span more than 8 tile rows (8 tails are staged)
+    if (cdiv(p.OH, 2) < 7) return false;      // ... or more than two images (the kernel's set-up handles one image wrap)
     for (int i = 0; i < p.nsrc; ++i)
         if (p.src[i].nch % 8 != 0) return false;
     return true;
