@@ -53,10 +53,34 @@ __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_
 constexpr int EPB_PITCH = 68;
 constexpr int EPB_WAVE_BYTES = 32 * EPB_PITCH * 4;          // 8704
 
+// The epilogue's (and the K loop's) kernel arguments are copied into locals up front and pinned in SGPRs (IGB_PIN): fetched where
+// they are used, every one of them is a scalar-load round trip behind the branch that needs it — dozens in a row per workgroup,
+// some of them once per K step (found with in-kernel stamps on the fp32 Winograd kernel).
+#define IGB_PIN(x) asm volatile("" : "+s"(x))
+struct IgEp {
+    int rw0, rw1, scatter, DC, OH, OW, DH, DW, dwy0, dwx0, M, cout, Nn, dn0, relu;
+    FastDiv d_ohw, d_ow;
+    const float *bias, *mask, *add;
+    float *dst;
+};
+__device__ __forceinline__ IgEp igb_epilogue_args(const IgemmP &p)
+{
+    IgEp e;
+    e.rw0 = p.rw0; e.rw1 = p.rw1; e.scatter = p.scatter; e.DC = p.DC; e.OH = p.OH; e.OW = p.OW; e.DH = p.DH; e.DW = p.DW;
+    e.dwy0 = p.dwy0; e.dwx0 = p.dwx0; e.M = p.M; e.cout = p.cout; e.Nn = p.Nn; e.dn0 = p.dn0; e.relu = p.relu;
+    e.d_ohw = p.d_ohw; e.d_ow = p.d_ow;
+    e.bias = p.bias; e.mask = p.mask; e.add = p.add; e.dst = p.dst;
+    IGB_PIN(e.rw0); IGB_PIN(e.rw1); IGB_PIN(e.scatter); IGB_PIN(e.DC); IGB_PIN(e.OH); IGB_PIN(e.OW); IGB_PIN(e.DH); IGB_PIN(e.DW);
+    IGB_PIN(e.dwy0); IGB_PIN(e.dwx0); IGB_PIN(e.M); IGB_PIN(e.cout); IGB_PIN(e.Nn); IGB_PIN(e.dn0); IGB_PIN(e.relu);
+    IGB_PIN(e.d_ohw.mul); IGB_PIN(e.d_ohw.shift); IGB_PIN(e.d_ow.mul); IGB_PIN(e.d_ow.shift);
+    IGB_PIN(e.bias); IGB_PIN(e.mask); IGB_PIN(e.add); IGB_PIN(e.dst);
+    return e;
+}
+
 // row tables of a linear-M tile: element offset of each tile row's pixel in dst | flags (bit 0: inside the deferred-ReLU
 // window, bit 1: row outside the output domain)
-template <int BM>
-__device__ __forceinline__ void igemmb_rows_linear(const IgemmP &p, int m0, int tid, unsigned *rowoff, unsigned char *rflag)
+template <int BM, class P>
+__device__ __forceinline__ void igemmb_rows_linear(const P &p, int m0, int tid, unsigned *rowoff, unsigned char *rflag)
 {
     if (tid < BM) {
         const bool relu_win = p.rw1 > p.rw0;
@@ -87,8 +111,8 @@ __device__ __forceinline__ void igemmb_rows_linear(const IgemmP &p, int m0, int 
 // The row tables must be complete (barrier) before the call; `patch` is the wave's private LDS area (EPB_WAVE_BYTES).
 // PF = row passes whose +add / mask operands are prefetched together (all of a slab's by default; the register-resident-filter
 // kernel below has fewer registers to spare)
-template <int TN, int PF = 0>
-__device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][TN], int wrow0, int n0w, int lane, float *patch,
+template <int TN, int PF = 0, class P = IgemmP>
+__device__ __forceinline__ void igemmb_store(const P &p, f32x16 (&acc)[2][TN], int wrow0, int n0w, int lane, float *patch,
                                              const unsigned *rowoff, const unsigned char *rflag)
 {
     constexpr int NL = 4 * TN;                 // lanes per row on the read-back side (8 channels each)
@@ -188,8 +212,8 @@ __device__ __forceinline__ void igemmb_store(const IgemmP &p, f32x16 (&acc)[2][T
     }
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
+template <int BM, int BN, class P>
+__device__ __forceinline__ void igemmb_epilogue(const P &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
 {
     constexpr int WN = BN / 64;
     unsigned *rowoff = (unsigned *)lds;
@@ -199,7 +223,7 @@ __device__ __forceinline__ void igemmb_epilogue(const IgemmP &p, f32x16 (&acc)[2
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    igemmb_store<2>(p, acc, wm * 64, n0 + wn * 64, lane, patch0 + wave * (EPB_WAVE_BYTES / 4), rowoff, rflag);
+    igemmb_store<2, 0, P>(p, acc, wm * 64, n0 + wn * 64, lane, patch0 + wave * (EPB_WAVE_BYTES / 4), rowoff, rflag);
 }
 
 // ---- plain kernel: every tap re-stages its A rows (up-conv GEMMs, and any 3x3 shape the halo kernel does not take) -------
@@ -217,6 +241,9 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const IgEp ep = igb_epilogue_args(p);
+    int a_TX = p.TX, a_T = p.T, a_nsrc = p.nsrc, a_oy0 = p.oy0, a_ox0 = p.ox0, a_stride = p.stride;
+    IGB_PIN(a_TX); IGB_PIN(a_T); IGB_PIN(a_nsrc); IGB_PIN(a_oy0); IGB_PIN(a_ox0); IGB_PIN(a_stride);
 
     int logical;
     {
@@ -248,17 +275,17 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
         const GSrc &g = p.src[si];
         sH = g.H; sW = g.W; sC = g.C; snch = g.nch;
         rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)g.p, 0, p.buf_bytes[si], 0x00020000);
-        const int ohw = p.OH * p.OW;
+        const int ohw = ep.OH * ep.OW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int m = m0 + srow + 32 * i;
-            m = m < p.M ? m : p.M - 1;
-            const int img = fdiv(m, p.d_ohw);
+            m = m < ep.M ? m : ep.M - 1;
+            const int img = fdiv(m, ep.d_ohw);
             const int rem = m - img * ohw;
-            const int oy = fdiv(rem, p.d_ow);
-            const int ox = rem - oy * p.OW;
-            const int iy = (oy + p.oy0) * p.stride - g.pad;
-            const int ix = (ox + p.ox0) * p.stride - g.pad;
+            const int oy = fdiv(rem, ep.d_ow);
+            const int ox = rem - oy * ep.OW;
+            const int iy = (oy + a_oy0) * a_stride - g.pad;
+            const int ix = (ox + a_ox0) * a_stride - g.pad;
             a_iy[i] = iy; a_ix[i] = ix;
             a_off[i] = (((img * g.H + iy) * g.W + ix) * g.C + g.c0 + coff) * 2;      // bytes
         }
@@ -287,19 +314,19 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
     // against taps outermost); the filter matrix keeps its [source][tap][channel] K order, so kglob is computed, not counted
     auto advance = [&]() {
         ++tx;
-        if (tx == p.TX) { tx = 0; ++ty; }
-        if (ty * p.TX + tx == p.T) {
+        if (tx == a_TX) { tx = 0; ++ty; }
+        if (ty * a_TX + tx == a_T) {
             ty = 0; tx = 0;
             kc += 64;
             if (kc == snch) {
                 kc = 0;
-                kbase += p.T * snch;
+                kbase += a_T * snch;
                 ++s;
-                if (s < p.nsrc) setup_source(s);
+                if (s < a_nsrc) setup_source(s);
             }
         }
         toff = (ty * sW + tx) * sC;
-        kglob = kbase + (ty * p.TX + tx) * snch + kc;
+        kglob = kbase + (ty * a_TX + tx) * snch + kc;
     };
 
     f32x16 acc[2][2];
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
         }
         __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
     }
-    igemmb_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
+    igemmb_epilogue<BM, BN>(ep, acc, m0, n0, tid, smem);
 }
 
 // =========================================================================================================================
