@@ -73,7 +73,7 @@ __device__ __forceinline__ IgEp igb_epilogue_args(const IgemmP &p)
     IGB_PIN(e.rw0); IGB_PIN(e.rw1); IGB_PIN(e.scatter); IGB_PIN(e.DC); IGB_PIN(e.OH); IGB_PIN(e.OW); IGB_PIN(e.DH); IGB_PIN(e.DW);
     IGB_PIN(e.dwy0); IGB_PIN(e.dwx0); IGB_PIN(e.M); IGB_PIN(e.cout); IGB_PIN(e.Nn); IGB_PIN(e.dn0); IGB_PIN(e.relu);
     IGB_PIN(e.d_ohw.mul); IGB_PIN(e.d_ohw.shift); IGB_PIN(e.d_ow.mul); IGB_PIN(e.d_ow.shift);
-    IGB_PIN(e.bias); IGB_PIN(e.mask); IGB_PIN(e.add); IGB_PIN(e.dst);
+    // (the pointers are not pinned: behind the asm they would be generic pointers, i.e. FLAT instructions)
     return e;
 }
 
