@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    // kernel arguments of the K loop and the epilogue, copied up front and pinned in SGPRs (igemm_epilogue.hpp)
+    const IgEp ep = igb_epilogue_args(p);
+    int a_TX = p.TX, a_T = p.T, a_nsrc = p.nsrc, a_oy0 = p.oy0, a_ox0 = p.ox0, a_stride = p.stride, a_ldw = p.ldw;
+    IGB_PIN(a_TX); IGB_PIN(a_T); IGB_PIN(a_nsrc); IGB_PIN(a_oy0); IGB_PIN(a_ox0); IGB_PIN(a_stride); IGB_PIN(a_ldw);
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give every XCD a
     // contiguous run of logical tiles; N-tiles of one M-tile are neighbours and reuse the A rows.
@@ -83,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         int n = n0 + srow + 32 * j;
-        n = n < p.Nn ? n : p.Nn - 1;
-        b_off[j] = n * p.ldw + coff;
+        n = n < ep.Nn ? n : ep.Nn - 1;
+        b_off[j] = n * a_ldw + coff;
     }
 
     int s = 0, ty = 0, tx = 0, kc = 0, kglob = 0;
@@ -99,17 +103,17 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
         const GSrc &g = p.src[si];
         sp = g.p; sH = g.H; sW = g.W; sC = g.C; snch = g.nch;
         if (BUF) rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)g.p, 0, p.buf_bytes[si], 0x00020000);
-        const int ohw = p.OH * p.OW;
+        const int ohw = ep.OH * ep.OW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int m = m0 + srow + 32 * i;
-            m = m < p.M ? m : p.M - 1;
-            const int img = fdiv(m, p.d_ohw);
+            m = m < ep.M ? m : ep.M - 1;
+            const int img = fdiv(m, ep.d_ohw);
             const int rem = m - img * ohw;
-            const int oy = fdiv(rem, p.d_ow);
-            const int ox = rem - oy * p.OW;
-            const int iy = (oy + p.oy0) * p.stride - g.pad;
-            const int ix = (ox + p.ox0) * p.stride - g.pad;
+            const int oy = fdiv(rem, ep.d_ow);
+            const int ox = rem - oy * ep.OW;
+            const int iy = (oy + a_oy0) * a_stride - g.pad;
+            const int ix = (ox + a_ox0) * a_stride - g.pad;
             a_iy[i] = iy; a_ix[i] = ix;
             a_off[i] = ((img * g.H + iy) * g.W + ix) * g.C + g.c0 + coff;
         }
@@ -154,11 +158,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
         if (kc == snch) {
             kc = 0;
             ++tx;
-            if (tx == p.TX) { tx = 0; ++ty; }
-            if (ty * p.TX + tx == p.T) {
+            if (tx == a_TX) { tx = 0; ++ty; }
+            if (ty * a_TX + tx == a_T) {
                 ty = 0; tx = 0;
                 ++s;
-                if (s < p.nsrc) setup_source(s);
+                if (s < a_nsrc) setup_source(s);
             } else {
                 toff = (ty * sW + tx) * sC;
             }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmP p)
         __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
     }
 
-    igemm_epilogue<BM, BN>(p, acc, m0, n0, tid, smem);
+    igemm_epilogue<BM, BN>(ep, acc, m0, n0, tid, smem);
 }
 
 // Algorithmic FLOPs of one launch: 2 * (in-bounds (pixel, tap) pairs) * channels * N.  Taps that fall

@@ -6,6 +6,31 @@ namespace unet {
 
 __device__ __forceinline__ int fdiv(int n, const FastDiv &f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift); }
 
+// The epilogue's (and the K loop's) kernel arguments are copied into locals up front and pinned in SGPRs (IGB_PIN): fetched where
+// they are used, every one of them is a scalar-load round trip behind the branch that needs it — dozens in a row per workgroup,
+// some of them once per K step (found with in-kernel stamps on the fp32 Winograd kernel).
+#define IGB_PIN(x) asm volatile("" : "+s"(x))
+struct IgEp {
+    int rw0, rw1, scatter, DC, OH, OW, DH, DW, dwy0, dwx0, M, cout, Nn, dn0, relu;
+    FastDiv d_ohw, d_ow;
+    const float *bias, *mask, *add;
+    float *dst;
+};
+__device__ __forceinline__ IgEp igb_epilogue_args(const IgemmP &p)
+{
+    IgEp e;
+    e.rw0 = p.rw0; e.rw1 = p.rw1; e.scatter = p.scatter; e.DC = p.DC; e.OH = p.OH; e.OW = p.OW; e.DH = p.DH; e.DW = p.DW;
+    e.dwy0 = p.dwy0; e.dwx0 = p.dwx0; e.M = p.M; e.cout = p.cout; e.Nn = p.Nn; e.dn0 = p.dn0; e.relu = p.relu;
+    e.d_ohw = p.d_ohw; e.d_ow = p.d_ow;
+    e.bias = p.bias; e.mask = p.mask; e.add = p.add; e.dst = p.dst;
+    IGB_PIN(e.rw0); IGB_PIN(e.rw1); IGB_PIN(e.scatter); IGB_PIN(e.DC); IGB_PIN(e.OH); IGB_PIN(e.OW); IGB_PIN(e.DH); IGB_PIN(e.DW);
+    IGB_PIN(e.dwy0); IGB_PIN(e.dwx0); IGB_PIN(e.M); IGB_PIN(e.cout); IGB_PIN(e.Nn); IGB_PIN(e.dn0); IGB_PIN(e.relu);
+    IGB_PIN(e.d_ohw.mul); IGB_PIN(e.d_ohw.shift); IGB_PIN(e.d_ow.mul); IGB_PIN(e.d_ow.shift);
+    // (the pointers are not pinned: behind the asm they would be generic pointers, i.e. FLAT instructions)
+    return e;
+}
+
+
 // ---- epilogue: bias / add / ReLU / mask / store with 16-byte accesses.
 // The MFMA accumulator layout gives a lane one column and 16 rows, i.e. dword stores (64 per lane; measured
 // ~4 us of store issue per workgroup, 18 % of a short-K layer).  Each wave therefore transposes its 32x32
@@ -16,8 +41,8 @@ constexpr int EPI_PITCH = 36;
 constexpr int EPI_WAVE_BYTES = 32 * EPI_PITCH * 4;
 
 // destination offset (+ deferred-ReLU flag) of tile row `i` into the LDS tables
-template <int BM>
-__device__ __forceinline__ void igemm_rowoff_entry(const IgemmP &p, int m0, int i, unsigned char *lds)
+template <int BM, class P>
+__device__ __forceinline__ void igemm_rowoff_entry(const P &p, int m0, int i, unsigned char *lds)
 {
     unsigned *rowoff = (unsigned *)lds;
     unsigned char *inwin = lds + BM * 4 + 4 * EPI_WAVE_BYTES;     // per-row flag: pixel inside the deferred-ReLU window
@@ -44,8 +69,8 @@ __device__ __forceinline__ void igemm_rowoff_entry(const IgemmP &p, int m0, int 
 }
 
 // stores of one consumer thread (tid in [0,256)); the row tables must be complete (barrier) before the call
-template <int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue_store(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid,
+template <int BM, int BN, class P>
+__device__ __forceinline__ void igemm_epilogue_store(const P &p, f32x16 (&acc)[2][2], int m0, int n0, int tid,
                                                      unsigned char *lds /* >= BM*5 + 4*EPI_WAVE_BYTES bytes */)
 {
     constexpr int WN = BN / 64;
@@ -122,8 +147,8 @@ __device__ __forceinline__ void igemm_epilogue_store(const IgemmP &p, f32x16 (&a
     }
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue(const IgemmP &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
+template <int BM, int BN, class P>
+__device__ __forceinline__ void igemm_epilogue(const P &p, f32x16 (&acc)[2][2], int m0, int n0, int tid, unsigned char *lds)
 {
     if (tid < BM) igemm_rowoff_entry<BM>(p, m0, tid, lds);
     __syncthreads();

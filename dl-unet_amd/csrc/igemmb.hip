@@ -53,30 +53,6 @@ __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_
 constexpr int EPB_PITCH = 68;
 constexpr int EPB_WAVE_BYTES = 32 * EPB_PITCH * 4;          // 8704
 
-// The epilogue's (and the K loop's) kernel arguments are copied into locals up front and pinned in SGPRs (IGB_PIN): fetched where
-// they are used, every one of them is a scalar-load round trip behind the branch that needs it — dozens in a row per workgroup,
-// some of them once per K step (found with in-kernel stamps on the fp32 Winograd kernel).
-#define IGB_PIN(x) asm volatile("" : "+s"(x))
-struct IgEp {
-    int rw0, rw1, scatter, DC, OH, OW, DH, DW, dwy0, dwx0, M, cout, Nn, dn0, relu;
-    FastDiv d_ohw, d_ow;
-    const float *bias, *mask, *add;
-    float *dst;
-};
-__device__ __forceinline__ IgEp igb_epilogue_args(const IgemmP &p)
-{
-    IgEp e;
-    e.rw0 = p.rw0; e.rw1 = p.rw1; e.scatter = p.scatter; e.DC = p.DC; e.OH = p.OH; e.OW = p.OW; e.DH = p.DH; e.DW = p.DW;
-    e.dwy0 = p.dwy0; e.dwx0 = p.dwx0; e.M = p.M; e.cout = p.cout; e.Nn = p.Nn; e.dn0 = p.dn0; e.relu = p.relu;
-    e.d_ohw = p.d_ohw; e.d_ow = p.d_ow;
-    e.bias = p.bias; e.mask = p.mask; e.add = p.add; e.dst = p.dst;
-    IGB_PIN(e.rw0); IGB_PIN(e.rw1); IGB_PIN(e.scatter); IGB_PIN(e.DC); IGB_PIN(e.OH); IGB_PIN(e.OW); IGB_PIN(e.DH); IGB_PIN(e.DW);
-    IGB_PIN(e.dwy0); IGB_PIN(e.dwx0); IGB_PIN(e.M); IGB_PIN(e.cout); IGB_PIN(e.Nn); IGB_PIN(e.dn0); IGB_PIN(e.relu);
-    IGB_PIN(e.d_ohw.mul); IGB_PIN(e.d_ohw.shift); IGB_PIN(e.d_ow.mul); IGB_PIN(e.d_ow.shift);
-    // (the pointers are not pinned: behind the asm they would be generic pointers, i.e. FLAT instructions)
-    return e;
-}
-
 // row tables of a linear-M tile: element offset of each tile row's pixel in dst | flags (bit 0: inside the deferred-ReLU
 // window, bit 1: row outside the output domain)
 template <int BM, class P>
