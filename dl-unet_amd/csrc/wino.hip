@@ -560,6 +560,10 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     q.d_tpi = make_fastdiv((unsigned)(q.tiles_x * q.tiles_y));
     q.d_tx = make_fastdiv((unsigned)q.tiles_x);
     q.p.mtiles = cdiv(q.MT, 64);
+    // the kernel's offset arithmetic multiplies rows by row pitches and columns by channel counts with 24-bit multiplies
+    for (int i = 0; i < p.nsrc; ++i)
+        ARG_CHECK((long)p.src[i].W * p.src[i].C < (1l << 23) && p.src[i].H < (1 << 22), "wino: source row pitch %ld exceeds the 24-bit multiply range", (long)p.src[i].W * p.src[i].C);
+    ARG_CHECK((long)(p.scatter == 2 ? p.DW : p.OW) * p.DC < (1l << 23), "wino: destination row pitch exceeds the 24-bit multiply range");
     q.p.ntiles = p.Nn / 32;
     // buffer-descriptor LDS-DMA needs every tensor below 2 GiB (32-bit num_records and the out-of-range marker);
     // larger tensors (config #5 at batch 16) and unet_set_lds_dma(0) take the global_load_lds instantiation
