@@ -18,8 +18,8 @@
 //   lane (channel l15, k = kg) reads its tiles' pixels channel-wise (ds_read_b32, 64 lanes = 256 contiguous bytes),
 //   V = B^T d B (32 packed adds), Z = A dY A^T up to signs (12 packed adds; the signs are applied in the reduce),
 //   and V[xi] / Z[xi] are exactly the A / B operands of the 16x16x4 MFMA (M = ci, N = cj, K = 4 tiles).
-// Partial dU slabs are reduced in a fixed order by wgradw_reduce_kernel, which also applies G^T . G and writes the
-// 3x3 gradient in the caller's layout; the fused bias gradient is the sum of the dz values a wave reads anyway.
+// Each workgroup applies the signs and G^T . G to its partial dU itself; the partial 3x3 slabs are reduced in a fixed order by
+// wgradw_reduce_kernel, which writes the gradient in the caller's layout; the fused bias gradient is the sum of the dz values a wave reads anyway.
 #include "common.hpp"
 #include "igemm_epilogue.hpp"
 #include <cstdio>
@@ -52,7 +52,7 @@ constexpr int WW_PATCH = 32768, WW_EXTRA = 2048, WW_DY = 16384;
 constexpr int WW_STAGE = WW_PATCH + WW_EXTRA + WW_DY;       // 51200
 constexpr int WW_NST = 3;
 constexpr int WW_LDS = WW_NST * WW_STAGE;                   // 153600
-constexpr int WW_SLAB = 16 * 64 * 64 + 64;                  // dU partial + bias partial (floats)
+constexpr int WW_SLAB = 9 * 64 * 64 + 64;                   // G^T dU G partial (3x3 taps) + bias partial (floats)
 
 template <int N> __device__ __forceinline__ void ww_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -353,15 +353,37 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
     }
 #undef WW_SB
 
-    // ---- slab: [xi 16][cj 64][ci 64] | db[64].  D lane layout: ci = 4*kg + r, cj = l15: ci is the fast index, so the four
-    // accumulator registers of a (xi, c) are one 16-byte store (32 store instructions per lane instead of 128 dword stores) and
-    // the reduce, with its threads along ci, writes the caller's OIHW gradient as consecutive 36-byte runs.
+    // ---- slab: [tap 9][cj 64][ci 64] | db[64]: the workgroup applies the signs and G^T . G to its partial itself (the slabs
+    // are 9/16 of the Winograd-domain ones: 29 MB less written by every launch's last wave of stores and read again by the
+    // reduce).  D lane layout: ci = 4*kg + r, cj = l15: ci is the fast index, so the four accumulator registers of a (tap, c)
+    // are one 16-byte store and the reduce, with its threads along ci, writes the caller's OIHW gradient as consecutive
+    // 36-byte runs.   r = G^T m (3x4), dg = r G (3x3);  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
     float *slab = p.slab + (size_t)(tile * k.nsplit + part) * k.pstride;
 #pragma unroll
-    for (int x = 0; x < 16; ++x)
+    for (int c = 0; c < 2; ++c) {
+        f32x4 r[3][4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            *(f32x4 *)(slab + (x * 64 + (2 * wj + c) * 16 + l15) * 64 + wi * 16 + 4 * kg) = acc[x][c];
+        for (int b = 0; b < 4; ++b) {
+            // signs of Z (load side): xi 3, 7, 11, 12, 13, 14 are negated
+            const f32x4 m0 = b == 3 ? -acc[b][c] : acc[b][c];
+            const f32x4 m1 = b == 3 ? -acc[4 + b][c] : acc[4 + b][c];
+            const f32x4 m2 = b == 3 ? -acc[8 + b][c] : acc[8 + b][c];
+            const f32x4 m3 = b == 3 ? acc[12 + b][c] : -acc[12 + b][c];
+            const f32x4 h = 0.5f * (m1 + m2);
+            r[0][b] = m0 + h;
+            r[1][b] = 0.5f * (m1 - m2);
+            r[2][b] = h + m3;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const f32x4 h = 0.5f * (r[a][1] + r[a][2]);
+            const f32x4 o0 = r[a][0] + h, o1 = 0.5f * (r[a][1] - r[a][2]), o2 = h + r[a][3];
+            float *dst = slab + ((a * 3) * 64 + (2 * wj + c) * 16 + l15) * 64 + wi * 16 + 4 * kg;
+            *(f32x4 *)(dst) = o0;
+            *(f32x4 *)(dst + 4096) = o1;
+            *(f32x4 *)(dst + 8192) = o2;
+        }
+    }
     if (wi == 0) {
         // bias partial: sum over this lane's tiles (.x + .y) and over the 4 k groups (lanes l15 + 16*kg)
 #pragma unroll
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void wgradw_f32_kernel(const WgradWK k)
             float v = dbacc[c][0] + dbacc[c][1];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (kg == 0) slab[16 * 64 * 64 + (2 * wj + c) * 16 + l15] = v;
+            if (kg == 0) slab[9 * 64 * 64 + (2 * wj + c) * 16 + l15] = v;
         }
     }
 }
@@ -386,57 +408,44 @@ __global__ __launch_bounds__(64 * PG) void wgradw_reduce_kernel(const float *__r
     const int tile = blockIdx.x >> 6, jb = blockIdx.x & 63;
     const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;          // j: this thread's ci within the tile
     const float *src = slab + (size_t)tile * nsplit * pstride + (size_t)jb * 64 + j;
-    float m[16];
+    float m[9];
 #pragma unroll
-    for (int x = 0; x < 16; ++x) m[x] = 0.f;
+    for (int x = 0; x < 9; ++x) m[x] = 0.f;
     for (int P = grp; P < nsplit; P += PG) {
         const float *s = src + (size_t)P * pstride;
 #pragma unroll
-        for (int x = 0; x < 16; ++x) m[x] += s[x * 4096];
+        for (int x = 0; x < 9; ++x) m[x] += s[x * 4096];
     }
-    __shared__ float red[PG][4][64];
-    // four passes of four xi through a 4 (16) KiB buffer
+    __shared__ float red[PG][3][64];
+    // three passes of three taps through a 3 (12) KiB buffer
 #pragma unroll
-    for (int xq = 0; xq < 4; ++xq) {
+    for (int xq = 0; xq < 3; ++xq) {
         if (xq) __syncthreads();
 #pragma unroll
-        for (int x = 0; x < 4; ++x) red[grp][x][j] = m[4 * xq + x];
+        for (int x = 0; x < 3; ++x) red[grp][x][j] = m[3 * xq + x];
         __syncthreads();
         if (grp == 0) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
+            for (int x = 0; x < 3; ++x) {
                 float v = red[0][x][j];
 #pragma unroll
                 for (int g = 1; g < PG; ++g) v += red[g][x][j];
-                m[4 * xq + x] = v;
+                m[3 * xq + x] = v;
             }
         }
     }
     if (grp == 0) {
-        m[3] = -m[3]; m[7] = -m[7]; m[11] = -m[11]; m[12] = -m[12]; m[13] = -m[13]; m[14] = -m[14];
-        // r = G^T m (3x4), dg = r G (3x3);  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
-        float r[3][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            r[0][c] = m[c] + 0.5f * (m[4 + c] + m[8 + c]);
-            r[1][c] = 0.5f * (m[4 + c] - m[8 + c]);
-            r[2][c] = 0.5f * (m[4 + c] + m[8 + c]) + m[12 + c];
-        }
         const int it = tile / ntile_j, jt = tile - it * ntile_j;
         float *o = out + (size_t)(it * 64 + j) * si + (size_t)(jt * 64 + jb) * sj;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            o[(a * 3 + 0) * st] = r[a][0] + 0.5f * (r[a][1] + r[a][2]);
-            o[(a * 3 + 1) * st] = 0.5f * (r[a][1] - r[a][2]);
-            o[(a * 3 + 2) * st] = 0.5f * (r[a][1] + r[a][2]) + r[a][3];
-        }
+        for (int t = 0; t < 9; ++t) o[t * st] = m[t];
     }
     if (db && jb == 0 && (tile / ntile_j) == 0) {
         // bias gradient of channel tile jt: slabs of the tiles (it = 0, jt)
         __syncthreads();
         const int jt = tile % ntile_j;
         float v = 0.f;
-        for (int P = grp; P < nsplit; P += PG) v += slab[((size_t)tile * nsplit + P) * pstride + 16 * 64 * 64 + j];
+        for (int P = grp; P < nsplit; P += PG) v += slab[((size_t)tile * nsplit + P) * pstride + 9 * 64 * 64 + j];
         red[grp][0][j] = v;
         __syncthreads();
         if (grp == 0) {
