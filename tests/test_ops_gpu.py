@@ -68,7 +68,9 @@ def conv_mode(hip, request):
 
 @pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 9, 128, 64), (1, 30, 32, 32),
                                      (3, 26, 128, 128), (1, 22, 256, 512), (2, 45, 64, 64),
-                                     (1, 66, 512, 512)])
+                                     (1, 66, 512, 512),
+                                     # minimal Winograd tile grids (9 x 9, 13 x 13 tiles per image): every 64-tile workgroup crosses an image boundary, ragged last one
+                                     (4, 20, 64, 64), (5, 28, 64, 128)])
 def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1); w = rnd(K, C, 3, 3, seed=2, scale=0.05); b = rnd(K, seed=3)
@@ -109,7 +111,7 @@ def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
 
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True),
                                                       (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False), (2, 25, 128, 256, True, True),
-                                                      (1, 66, 512, 512, True, True)])
+                                                      (1, 66, 512, 512, True, True), (4, 20, 64, 64, True, True)])
 def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1).requires_grad_(True)
