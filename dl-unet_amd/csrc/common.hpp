@@ -32,6 +32,7 @@ enum { PK_IGEMM = 0, PK_WGRAD = 1, PK_REDUCE = 2, PK_WINO = 3, PK_STENCIL = 4, P
 void prof_scope(const char *row);
 void prof_begin(int kind, const char *tag, hipStream_t st, double alg_flops, double exec_flops, double alg_bytes);
 void prof_end(hipStream_t st);
+bool prof_active();          // per-launch events are being recorded (concurrent streams would blur them: the overlap knob stays off)
 struct ProfScope {          // RAII: names the row for the launches of a block
     explicit ProfScope(const char *row) { prof_scope(row); }
     ~ProfScope() { prof_scope(nullptr); }

@@ -152,7 +152,14 @@ static size_t layer_numel(int base, int layer, bool bias)
 static size_t layer_wino_floats(int base, int layer)
 {
     if (layer == C11C || layer == UP4 || layer == UP3 || layer == UP2 || layer == UP1 || layer == FINAL) return 0;
-    return layer_numel(base, layer, false) / 9 * 16;
+    // U is kept in whole 64-row blocks (wino_u_floats); forward: rows = output channels, one sub-matrix per source of the
+    // virtual concat; dgrad: rows = input channels, one launch (and sub-matrix) per source.  The larger of the two directions.
+    const size_t co = layer_numel(base, layer, true);
+    const size_t ci = layer_numel(base, layer, false) / 9 / co;
+    const bool two = layer == C11E || layer == C21E || layer == C31E || layer == C41E;
+    const size_t fwd = wino_u_floats((int)ci, (int)co);
+    const size_t bwd = two ? 2 * wino_u_floats((int)co, (int)(ci / 2)) : wino_u_floats((int)co, (int)ci);
+    return fwd > bwd ? fwd : bwd;
 }
 
 // One 3x3 layer's reference (OIHW) weights and their packed igemm copy.  The copy is made on first need: in math mode 3
@@ -684,25 +691,33 @@ int unet_backward_stage_params(int stage, int *idx, int cap)
 // weight gradient must be enqueued BEFORE the dgrad it is to run next to.
 struct WgradStream {
     unet_handle *h; hipStream_t main; bool overlap; bool used;
+    hipError_t err = hipSuccess;     // sticky: a failed fork / join means the two streams are not ordered - the stage must not report success
     hipStream_t get()
     {
         if (!overlap) return main;
-        (void)hipEventRecord(h->ev_fork, main);
-        (void)hipStreamWaitEvent(h->aux, h->ev_fork, 0);
+        // fork failed: the weight gradient stays on the caller's stream (ordered by construction)
+        hipError_t e = hipEventRecord(h->ev_fork, main);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->aux, h->ev_fork, 0);
+        if (e != hipSuccess) { if (err == hipSuccess) err = e; overlap = false; return main; }
         used = true;
         return h->aux;
     }
     void join()
     {
         if (!used) return;
-        (void)hipEventRecord(h->ev_join, h->aux);
-        (void)hipStreamWaitEvent(main, h->ev_join, 0);
+        hipError_t e = hipEventRecord(h->ev_join, h->aux);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, h->ev_join, 0);
+        if (e != hipSuccess) {
+            // last resort: the caller's stream cannot be made to wait, so the host waits for the auxiliary stream
+            (void)hipStreamSynchronize(h->aux);
+            if (err == hipSuccess) err = e;
+        }
         used = false;
     }
 };
 static thread_local WgradStream *t_wst = nullptr;
 static inline hipStream_t wgrad_stream(hipStream_t st) { return t_wst ? t_wst->get() : st; }
-static inline hipStream_t wst_same(hipStream_t st) { return (t_wst && t_wst->overlap) ? t_wst->h->aux : st; }   // right after a wgrad_stream() call
+static inline hipStream_t wst_same(hipStream_t st) { return (t_wst && t_wst->overlap && t_wst->used) ? t_wst->h->aux : st; }   // right after a wgrad_stream() call
 
 static int conv_backward(const Plan &pl, void *workspace, hipStream_t st, const void *const *params, void *const *grads,
                          int layer, const float *X, int XH, int C, const float *dz, int Ho, int K,
@@ -733,6 +748,9 @@ static int pool_backward(const Plan &pl, void *workspace, int l, void *stream)
     return maxpool2_bwd(WS(pl.a2[l]), WS(pl.g_t[l]), WS(pl.g_a2[l]), pl.B, pl.ea2[l], pl.ea2[l], pl.ch[l], t_es, (hipStream_t)stream);
 }
 
+static int backward_stage_body(unet_handle *h, const Plan &pl, int stage, const void *const *params, const void *dlogits, void *const *grads,
+                               void *workspace, void *stream);
+
 int unet_backward_stage(unet_handle *h, int stage, const void *const *params, const void *dlogits, void *const *grads,
                         void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -746,21 +764,32 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
     ARG_CHECK(workspace_bytes >= pl.total, "unet_backward: workspace too small");
     ARG_CHECK(stage >= 0 && stage < N_STAGES, "unet_backward: bad stage %d", stage);
     MathScope ms(pl.math);                   // the arithmetic the forward was planned with
-    hipStream_t st = (hipStream_t)stream;
-    const int B = pl.B;
-    const int *ch = pl.ch;
-    int rc;
-    if (g_overlap && !h->aux) {
+    // (no overlap while per-launch events are recorded: launches of two streams would interleave their begin / end events)
+    const bool overlap = g_overlap != 0 && !prof_active();
+    if (overlap && !h->aux) {
         HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
-    WgradStream wst{h, st, g_overlap != 0, false};
-    struct Scope {                           // every return path re-joins the streams before the caller sees the stage as enqueued
-        WgradStream &w;
-        explicit Scope(WgradStream &w_) : w(w_) { t_wst = &w; }
-        ~Scope() { w.join(); t_wst = nullptr; }
-    } scope(wst);
+    WgradStream wst{h, (hipStream_t)stream, overlap, false};
+    t_wst = &wst;
+    int rc = backward_stage_body(h, pl, stage, params, dlogits, grads, workspace, stream);
+    wst.join();                              // every path re-joins the streams before the caller sees the stage as enqueued
+    t_wst = nullptr;
+    if (rc == 0 && wst.err != hipSuccess) {
+        set_error("unet_backward: ordering the weight-gradient stream against the caller's failed: %s", hipGetErrorString(wst.err));
+        rc = (int)wst.err;
+    }
+    return rc;
+}
+
+static int backward_stage_body(unet_handle *h, const Plan &pl, int stage, const void *const *params, const void *dlogits, void *const *grads,
+                               void *workspace, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int B = pl.B;
+    const int *ch = pl.ch;
+    int rc;
 
     if (stage < 4) {
         const int l = stage;
@@ -888,7 +917,14 @@ static size_t upconv_slab_bound(int B, int H, int Ci, int Co)
 }
 
 // ---- per-op entry points (unit tests) --------------------------------------------------------------
-size_t unet_conv3x3_scratch_bytes(int C, int K) { return align_up((size_t)K * C * 9 * sizeof(float), 256) + align_up((size_t)K * C * 16 * sizeof(float), 256); }
+static size_t wino_scratch_bytes(int C, int K)
+{
+    // U of a per-op call, whole 64-row blocks (wino_u_floats): forward 16 C rup64(K) (the sources' sub-matrices add up to it);
+    // dgrad one sub-matrix per source, 16 K (rup64(C1) + rup64(C2)) <= 16 K (rup64(C) + 64)
+    const size_t fwd = wino_u_floats(C, K), bwd = wino_u_floats(K, C) + wino_u_floats(K, 64);
+    return align_up((fwd > bwd ? fwd : bwd) * sizeof(float), 256);
+}
+size_t unet_conv3x3_scratch_bytes(int C, int K) { return align_up((size_t)K * C * 9 * sizeof(float), 256) + wino_scratch_bytes(C, K); }
 
 int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2, int B, int H, int W,
                      const void *w_oihw, const void *bias, int K, int relu, void *y, void *scratch, void *stream)
@@ -908,7 +944,7 @@ int unet_conv3x3_fwd(const void *x1, int H1, int W1, int C1, int pad1, const voi
 size_t unet_conv3x3_bwd_scratch_bytes(int B, int H, int W, int C, int K)
 {
     return align_up((size_t)K * C * 9 * sizeof(float), 256) + conv_bwd_slab_bound(B, H, C, K) +
-           align_up(bias_grad_scratch_bytes((size_t)B * (H - 2) * (W - 2), K), 256) + align_up((size_t)K * C * 16 * sizeof(float), 256);
+           align_up(bias_grad_scratch_bytes((size_t)B * (H - 2) * (W - 2), K), 256) + wino_scratch_bytes(C, K);
 }
 
 int unet_conv3x3_bwd(const void *x1, int H1, int W1, int C1, int pad1, const void *x2, int C2, int B, int H, int W,

@@ -56,6 +56,8 @@ void prof_begin(int kind, const char *tag, hipStream_t st, double alg_flops, dou
     g_open = true;
 }
 
+bool prof_active() { return g_on; }
+
 void prof_end(hipStream_t st)
 {
     if (!g_on) return;

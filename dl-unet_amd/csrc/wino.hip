@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void wino_transform_ref_kernel(const float *__
 
 int wino_transform_ref(const float *w_oihw, int I, int dgrad, int n0, int Nn, int k0, int Kc, float *U, hipStream_t st)
 {
-    ARG_CHECK(w_oihw && U && Nn % 64 == 0 && Kc % 8 == 0 && Kc > 0, "wino_transform_ref: bad shape");
+    ARG_CHECK(w_oihw && U && Nn % 32 == 0 && Kc % 8 == 0 && Kc > 0, "wino_transform_ref: bad shape");      // (U is allocated in whole 64-row blocks: wino_u_floats)
     const size_t total = (size_t)Nn * Kc;
     hipLaunchKernelGGL(wino_transform_ref_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, I, dgrad, n0, Nn, k0, Kc, U);
     HIP_TRY(hipGetLastError());
@@ -528,15 +528,22 @@ __global__ __launch_bounds__(256, 2) void wino32_f32_kernel(const WinoP k)
 bool wino_applicable(const IgemmP &p)
 {
     if (p.T != 9 || p.TX != 3 || p.stride != 1 || p.scatter == 1) return false;
-    if (p.Nn % 64 != 0) return false;
+    if (p.Nn % 32 != 0) return false;         // a workgroup owns 32 filter rows (half a 64-row block of U; a last half block stays unused)
     if (cdiv(p.OW, 2) < 9) return false;      // a workgroup's 64 linear tiles may then span more than 8 tile rows (8 tails are staged)
     if (cdiv(p.OH, 2) < 7) return false;      // ... or more than two images (the kernel's set-up handles one image wrap)
     for (int i = 0; i < p.nsrc; ++i)
         if (p.src[i].nch % 8 != 0) return false;
+    // ranges of the kernel's offset arithmetic: rows x row pitch and columns x channels are 24-bit multiplies, and the tile
+    // decomposition x / tiles_x is an exact float floor only for tiles_x < 2^12.  A shape beyond them takes the implicit GEMM
+    // (launch_wino keeps the same conditions as internal assertions)
+    for (int i = 0; i < p.nsrc; ++i)
+        if ((long)p.src[i].W * p.src[i].C >= (1l << 23) || p.src[i].H >= (1 << 22)) return false;
+    if ((long)(p.scatter == 2 ? p.DW : p.OW) * p.DC >= (1l << 23)) return false;
+    if (cdiv(p.OW, 2) >= (1 << 12)) return false;
     return true;
 }
 
-size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * Nn; }
+size_t wino_u_floats(int Kc, int Nn) { return (size_t)16 * Kc * ((Nn + 63) / 64 * 64); }     // whole 64-row blocks
 
 // true iff launch_igemm will hand this 3x3 launch to the Winograd kernel with an epilogue that can also write the 2x2
 // max-pool of its output (IgemmP::pool_dst)
@@ -564,6 +571,7 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
     for (int i = 0; i < p.nsrc; ++i)
         ARG_CHECK((long)p.src[i].W * p.src[i].C < (1l << 23) && p.src[i].H < (1 << 22), "wino: source row pitch %ld exceeds the 24-bit multiply range", (long)p.src[i].W * p.src[i].C);
     ARG_CHECK((long)(p.scatter == 2 ? p.DW : p.OW) * p.DC < (1l << 23), "wino: destination row pitch exceeds the 24-bit multiply range");
+    ARG_CHECK(q.tiles_x < (1 << 12), "wino: %d tile columns exceed the exact range of the float-floor tile decomposition", q.tiles_x);
     q.p.ntiles = p.Nn / 32;
     // buffer-descriptor LDS-DMA needs every tensor below 2 GiB (32-bit num_records and the out-of-range marker);
     // larger tensors (config #5 at batch 16) and unet_set_lds_dma(0) take the global_load_lds instantiation

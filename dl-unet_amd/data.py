@@ -71,12 +71,15 @@ def elastic_transform(images, alpha, sigma, random_state=None, fields=None):
     ref = _as_batch(images[0]).contiguous().float()
     B, H, W = ref.shape
     dev = ref.device
+    # (host arrays are narrowed to fp32 by numpy: a torch CPU op on half a million elements goes through the intra-op thread
+    #  pool, which on a GPU host's share of cores costs tens of milliseconds per call - measured 54 ms for one .float())
     if fields is not None:
-        f0, f1 = [torch.as_tensor(f, dtype=torch.float32, device=dev).reshape(B, H, W).contiguous() for f in fields]
+        f0, f1 = [(f.to(dev, torch.float32) if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f, dtype=np.float32)).to(dev))
+                  .reshape(B, H, W).contiguous() for f in fields]
     elif random_state is not None:
         draws = [(random_state.rand(H, W), random_state.rand(H, W)) for _ in range(B)]    # per sample: dx field, then dy field
-        f0 = torch.from_numpy(np.stack([d[0] for d in draws])).float().to(dev)
-        f1 = torch.from_numpy(np.stack([d[1] for d in draws])).float().to(dev)
+        f0 = torch.from_numpy(np.stack([d[0] for d in draws]).astype(np.float32)).to(dev)
+        f1 = torch.from_numpy(np.stack([d[1] for d in draws]).astype(np.float32)).to(dev)
     else:
         f0 = torch.rand(B, H, W, device=dev); f1 = torch.rand(B, H, W, device=dev)
     w, radius = gaussian_taps(sigma)
@@ -137,6 +140,11 @@ def augment(image, target, crop_xy, crop, rot_deg, alpha, sigma, random_state=No
     _, S, _ = input_size_compute(img)
     both = reflect_rotate_crop(torch.stack((img.float(), tgt.float())), [rot_deg, rot_deg], S, levels=levels)
     inp, gt = elastic_transform((both[0], both[1]), alpha, sigma, random_state=random_state, fields=fields)
+    if levels:
+        # the reference warps the uint8 / uint16 arrays it loaded: scipy's map_coordinates writes its result in the input's
+        # type, i.e. rounds t + 0.5 down and clamps to the type's range (data.py:245 on the rotated integer images)
+        inp = torch.floor(inp + 0.5).clamp_(0, levels)
+        gt = torch.floor(gt + 0.5).clamp_(0, levels)
     pad = int((S - crop) / 2)
     gt = (gt[pad:crop + pad, pad:crop + pad] > 127).long()
     lo, hi = inp.min(), inp.max()

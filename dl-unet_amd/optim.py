@@ -58,13 +58,14 @@ class _BCEStepFn(torch.autograd.Function):
     def forward(ctx, logits, labels, weight, wstrides, grad_scale, want_mask):
         B, two, H, W = logits.shape
         assert two == 2
+        # (read before any copy: forward runs with grad mode off, so a contiguous() copy never requires grad)
+        need_grad = ctx.needs_input_grad[0]
         if logits.stride(3) != 1:
             logits = logits.contiguous()
         labels = labels.to(logits.device).reshape(B, H, W).contiguous()
         if labels.dtype != torch.int64:
             labels = labels.long()
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        need_grad = logits.requires_grad
         dl = torch.empty(B, 2, H, W, dtype=torch.float32, device=logits.device) if need_grad else None
         mask = torch.empty(B, H, W, dtype=torch.int64, device=logits.device) if want_mask else None
         sc = torch.empty(_hip.lib().unet_bce_step_scratch_bytes(B * H * W), dtype=torch.uint8, device=logits.device)

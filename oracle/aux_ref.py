@@ -83,3 +83,31 @@ def reflect_rotate_crop(image, rot_deg, input_size=None):
     l = w // 2 - input_size // 2; r = w // 2 + input_size // 2
     t = h // 2 - input_size // 2; b = h // 2 + input_size // 2
     return rot[t:b, l:r]
+
+
+def cells(seed, n=512):
+    """The synthetic 'cell' sample of tests/golden/make_golden_augment.py (BASELINE configs[3] shape): 12 discs on a noisy
+    background, from the libm-free PRNG so that the GPU box regenerates it: (uint8 image [n,n], {0,255} uint8 mask [n,n])."""
+    from . import prng
+    u = prng.uniform01(21, seed, 36)
+    yy, xx = np.mgrid[0:n, 0:n]
+    mask = np.zeros((n, n), bool)
+    for i in range(12):
+        cy, cx, r = 40 + u[3 * i] * (n - 80), 40 + u[3 * i + 1] * (n - 80), 15 + u[3 * i + 2] * 30
+        mask |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+    noise = prng.uniform01(22, seed, n * n).reshape(n, n)
+    img = np.floor((0.3 + 0.5 * mask + 0.1 * noise) * 255).astype(np.uint8)
+    return img, (mask * 255).astype(np.uint8)
+
+
+def augment(image, target, rot_deg, alpha, sigma, random_state):
+    """ImageDataset.__getitem__ after the crop (data.py:103-134) for one sample: reflect pad + rotation + centre crop, the same
+    elastic deformation for image and mask (fields drawn from random_state: dx field, then dy field), mask cropped to the label
+    extent (returned BEFORE the 127 threshold, as grey levels) and the image normalised to [0,1]."""
+    n = image.shape[-1]
+    _, S, _ = input_size_compute(n)
+    ri, rt = reflect_rotate_crop(image, rot_deg), reflect_rotate_crop(target, rot_deg)
+    f0 = random_state.rand(S, S); f1 = random_state.rand(S, S)
+    (ei, et), _, _ = elastic_transform((ri, rt), alpha, sigma, (f0, f1))
+    pad = int((S - n) / 2)
+    return normalise01(ei), et[pad:n + pad, pad:n + pad]

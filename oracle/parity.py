@@ -216,3 +216,38 @@ def shadow_training(net, train, val, epochs_arg, batch_size=2, lr=1e-4, mu=0.99,
             side["val_eval_iou"].append(v[0]); side["val_eval_pe"].append(v[1])
     final = max(nerr(v.detach().cpu().numpy(), p64[k]) for k, v in net.named_parameters())
     return hip, ref, final
+
+
+# ---- bf16 tensors (arithmetic mode 2, BASELINE configs[2]): the error model the S=572 test holds the path to ---------------------
+# Storage roundings on the longest path input -> logits (network.py:129-192; 23 layers):
+#   * 22 layer outputs are stored as bf16 (every conv / up-conv output; the head's logits stay fp32, pooling picks a stored value);
+#   * 21 layers read bf16 copies of their filters (conv11c and the head multiply by the fp32 parameters).
+# One round-to-nearest to bf16's 8 significant bits is a relative error uniform in [-u, u], u = 2^-8: variance u^2 / 3.
+# First order, independent roundings: the output rounding adds u^2/3 to an element's relative variance; the filter roundings add
+# (u^2/3) sum_k (w_k a_k)^2 / (sum_k w_k a_k)^2 = u^2/3 for terms of random sign (no systematic cancellation at the reference's
+# random init: the tests below check this premise by emulation); a layer passes its input's relative error on with unit gain
+# (it is linear up to the ReLU/pool selection, and relative error does not see the layer's scale).  Hence
+#       sigma_rel = u sqrt((22 + 21) / 3) = 1.48e-2
+# of an element's typical magnitude (the tensor's rms), and over N elements the largest error is the Gaussian tail
+#       max |err| <= sqrt(2 ln N) sigma_rel rms(tensor).
+BF16_U = 2.0 ** -8
+BF16_ROUNDED_OUTPUTS = 22
+BF16_ROUNDED_FILTERS = 21
+
+
+def bf16_sigma_rel(outputs=BF16_ROUNDED_OUTPUTS, filters=BF16_ROUNDED_FILTERS):
+    return BF16_U * np.sqrt((outputs + filters) / 3.0)
+
+
+def bf16_max_err(n_elements, rms, outputs=BF16_ROUNDED_OUTPUTS, filters=BF16_ROUNDED_FILTERS):
+    """Largest absolute error the model allows among n_elements values of a tensor with the given rms."""
+    return float(np.sqrt(2.0 * np.log(max(int(n_elements), 2))) * bf16_sigma_rel(outputs, filters) * rms)
+
+
+def bf16_expected_flips(margins, sigma_abs):
+    """Expected number (and its standard deviation) of sign changes of `margins` under independent N(0, sigma_abs) errors."""
+    from math import erfc, sqrt
+    m = np.abs(np.asarray(margins, dtype=np.float64).ravel())
+    m = m[m < 8 * sigma_abs]
+    pr = np.array([0.5 * erfc(v / (sigma_abs * sqrt(2.0))) for v in m])
+    return float(pr.sum()), float(np.sqrt((pr * (1 - pr)).sum()))

@@ -16,16 +16,25 @@ def crop_and_concat(A, B):
     return torch.cat((F.pad(A, (-c, -c, -c, -c)), B), 1)
 
 
-def unet_forward(p, t, pre=None):
-    """pre: optional dict that receives every ReLU'd conv's PRE-activation by layer name (branch analysis in the tests)."""
+def unet_forward(p, t, pre=None, store=None, wstore=None):
+    """pre: optional dict that receives every ReLU'd conv's PRE-activation by layer name (branch analysis in the tests).
+    store / wstore: optional emulation of a reduced-precision tensor format: store(x) is applied to every conv / up-conv output
+    as it would be written to memory (after bias and ReLU), wstore(w) to the filters of every layer but conv11c and the head -
+    the roundings of the HIP path's bf16-tensor mode (oracle/parity.py, bf16 error model)."""
+    store = store or (lambda v: v)
+
+    def wt(name):
+        w = p[name + ".weight"]
+        return wstore(w) if wstore is not None and name not in ("conv11c", "finalconv") else w
+
     def cr(name, t):
-        z = F.conv2d(t, p[name + ".weight"], p[name + ".bias"])
+        z = F.conv2d(t, wt(name), p[name + ".bias"])
         if pre is not None:
             pre[name] = z.detach()
-        return F.relu(z)
+        return store(F.relu(z))
 
     def up(name, t):
-        return F.conv_transpose2d(t, p[name + ".weight"], p[name + ".bias"], stride=2)
+        return store(F.conv_transpose2d(t, wt(name), p[name + ".bias"], stride=2))
 
     skips = []
     for lvl in "1234":

@@ -88,6 +88,29 @@ def main_s572_grad():
     print("S=572 gradients done: reference's own fp32-vs-fp64 distance per tensor: worst %.3g (%s)" % (e.max(), names[int(e.argmax())]))
 
 
+def main_s572_margin():
+    """G3c: the class margin d = logit1 - logit0 of the reference's fp64 forward at S=572, B=1, for EVERY output pixel
+    (float32, 602 KB): what a reduced-precision path (bf16 tensors, BASELINE configs[2]) needs to show that each argmax
+    pixel it flips sat closer to the decision boundary than its own error bound (unet_S572_margin.npz).
+    Run:  python tests/golden/make_golden.py s572margin"""
+    network, _ = import_reference()
+    torch.set_num_threads(8)
+    S, B = 572, 1
+    params = prng.make_params(seed=0)
+    x = prng.make_input(1, B, S)
+    r64 = run_net(network, params, x, None, torch.float64)["logits"]
+    d = r64[:, 1] - r64[:, 0]
+    g = np.load(os.path.join(HERE, "unet_S572_fwd.npz"))
+    assert np.array_equal(np.packbits((d > 0).ravel()), g["argmax_packed"]), "the fp64 forward no longer reproduces unet_S572_fwd.npz"
+    fx = {"meta": np.array(repr(dict(torch=torch.__version__, threads=torch.get_num_threads(), seed_w=0, S=S, B=B, seed_x=1))),
+          "margin_f64_as_f32": d.astype(np.float32),
+          "margin_rms": np.array(np.sqrt((d * d).mean())),
+          "logits_absmax": np.array(np.abs(r64).max()),
+          "logits_rms": np.array(np.sqrt((r64 * r64).mean()))}
+    np.savez_compressed(os.path.join(HERE, "unet_S572_margin.npz"), **fx)
+    print("S=572 margins done: rms %.4g, |d| < 1: %d px, < 10: %d px of %d" % (fx["margin_rms"], (np.abs(d) < 1).sum(), (np.abs(d) < 10).sum(), d.size))
+
+
 def main():
     network, functions = import_reference()
     torch.set_num_threads(8)
@@ -203,5 +226,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "s572grad":
         main_s572_grad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "s572margin":
+        main_s572_margin()
     else:
         main()

@@ -237,12 +237,12 @@ def test_augment_pipeline_on_device(dev):
     f0, f1 = rs.rand(S, S), rs.rand(S, S)
     inp, gt = data.augment(torch.from_numpy(img.astype(np.float32)).to(dev), torch.from_numpy(tgt.astype(np.float32)).to(dev),
                            (x0, y0), crop, deg, alpha, sigma, fields=(f0, f1))
-    ri = aux_ref.reflect_rotate_crop(img[x0:x0 + crop, y0:y0 + crop], deg)
-    rt = aux_ref.reflect_rotate_crop(tgt[x0:x0 + crop, y0:y0 + crop], deg)
-    (ei, et), _, _ = aux_ref.elastic_transform((ri.astype(np.float64), rt.astype(np.float64)), alpha, sigma, (f0, f1))
-    pad = (S - crop) // 2
-    gt_ref = (et[pad:pad + crop, pad:pad + crop] > 127).astype(np.int64)
-    inp_ref = aux_ref.normalise01(ei)
+    # the oracle works on the uint8 arrays like the reference (scipy writes rotation and warp results in the input's type)
+    rs2 = np.random.RandomState(77)
+    inp_ref, et = aux_ref.augment(img[x0:x0 + crop, y0:y0 + crop], tgt[x0:x0 + crop, y0:y0 + crop], deg, alpha, sigma, rs2)
+    gt_ref = (et > 127).astype(np.int64)
     assert inp.shape == (1, S, S) and gt.shape == (1, crop, crop) and gt.dtype == torch.int64
-    assert np.abs(inp.cpu().numpy()[0] - inp_ref).max() < 1.5 / 255              # one grey level (a rounding flip) at most
+    # two roundings to grey levels on the way (rotation, warp), each of which a value within fp32 noise of k + 0.5 may flip
+    d = np.abs(inp.cpu().numpy()[0] - inp_ref)
+    assert d.max() < 2.5 / 255 and (d > 0.6 / 255).mean() < 2e-2, (d.max(), (d > 0.6 / 255).mean())
     assert (gt.cpu().numpy()[0] != gt_ref).mean() < 5e-3

@@ -61,3 +61,18 @@ def test_reflect_rotate_crop_oracle_vs_reference_golden(golden_dir):
         assert ri.shape == (S, S) and ri.dtype == np.uint8
         assert np.array_equal(ri[::st, ::st], g["%s_img_sample" % tag]) and np.array_equal(rt[::st, ::st], g["%s_tgt_sample" % tag])
         assert [int(ri.astype(np.int64).sum()), int(rt.astype(np.int64).sum())] == [int(v) for v in g["%s_sums" % tag]]
+
+
+def test_augment_oracle_at_the_config4_size_vs_reference_golden(golden_dir):
+    """BASELINE configs[3] shape (512^2 sample -> 700^2 input): oracle/aux_ref.augment against tests/golden/augment_golden_S700.npz,
+    made by executing the reference's own __getitem__ statements and elastic_transform (make_golden_augment.py): rotation angle
+    as the reference drew it (330 and 0 degrees), alpha = 200, sigma = 10, the RandomState the reference would have created."""
+    g = np.load(os.path.join(golden_dir, "augment_golden_S700.npz"))
+    for tag in ("a", "b"):
+        crop, seed, deg, S, eseed, _ = [int(v) for v in g["%s_params" % tag]]
+        img, tgt = aux_ref.cells(seed, crop)
+        inp, gt = aux_ref.augment(img, tgt, deg, 200, 10, np.random.RandomState(eseed))
+        assert inp.shape == (S, S) and gt.shape == (crop, crop)
+        assert np.abs(inp[::5, ::5] - g["%s_inp_sample" % tag]).max() < 1e-6          # the fixture is float32
+        assert np.abs(gt[::4, ::4] - g["%s_gt_sample" % tag]).max() < 1e-3
+        assert np.allclose([inp.sum(), (inp * inp).sum(), gt.sum(), float((gt > 127).sum())], g["%s_sums" % tag], rtol=1e-12)

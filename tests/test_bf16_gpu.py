@@ -2,6 +2,8 @@
 kernels through the C ABI.  Inputs and weights are bf16-representable, so the fp64 reference sees exactly the operands
 the kernels see: what remains is fp32 accumulation (gradients w.r.t. parameters stay fp32: tolerance 2e-5 as in fp32) and
 ONE rounding of each bf16 output (half an ulp: 8 significant bits, at most 2^-8 = 3.9e-3 of the element and so of the tensor scale: tolerance 4e-3)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -228,3 +230,47 @@ def test_bf16_weight_gradient_refuses_tensors_of_2GiB_loudly(hip):
     with pytest.raises(RuntimeError, match="2 GiB"):
         hip.check(rc, "conv3x3_bwd")
     assert bool((dw == 7.0).all()) and bool((db == 7.0).all())
+
+
+def test_bf16_tensors_at_the_baseline_tile_against_the_reference_golden(hip, golden_dir):
+    """BASELINE configs[2] arithmetic (bf16 tensors, mode 2) at the BASELINE tile, S = 572, against the reference's fp64 run
+    (tests/golden/unet_S572_fwd.npz: logits samples; unet_S572_margin.npz: the class margin d = logit1 - logit0 of every pixel).
+    The north_star's "within 1e-3, argmax bit-exact" is an fp32 tolerance: 8-bit significands cannot meet it,
+    so this mode is held to the bound bf16 storage itself implies - DERIVED, not fitted (oracle/parity.py, checked against an
+    emulation on the CPU by tests/test_oracle_golden.py):
+        sigma_rel = 2^-8 sqrt((22 stored outputs + 21 rounded filter sets) / 3) = 1.48e-2        (of a tensor's rms)
+        max over N elements <= sqrt(2 ln N) sigma_rel rms
+    (1) sampled logits within that bound; (2) the margin d of EVERY pixel within it; (3) every pixel whose argmax differs from
+    the reference's has an fp64 margin below the bound - no flip away from the decision boundary; (4) the number of flips is
+    what N(0, sigma_rel rms(d)) errors would produce on the fixture's own margin distribution (mean + 4 sd)."""
+    import network
+    from oracle import parity, prng
+    f = np.load(os.path.join(golden_dir, "unet_S572_fwd.npz"))
+    m = np.load(os.path.join(golden_dir, "unet_S572_margin.npz"))
+    net = network.Unet()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in prng.make_params(0).items()})
+    net = net.to("cuda:0")
+    with torch.no_grad():
+        y = net(torch.from_numpy(prng.make_input(1, 1, 572)).cuda()).double().cpu().numpy()
+    assert hip.lib().unet_get_math() == 2
+    # (1) logits, 2 x 65 x 65 strided samples
+    ref_s = f["logits_sample_f64"]
+    rms_y = float(m["logits_rms"])
+    b_log = parity.bf16_max_err(ref_s.size, rms_y)
+    e_log = float(np.abs(y[:, :, ::6, ::6] - ref_s).max())
+    # (2) margins, all 150,544 pixels
+    d_ref = m["margin_f64_as_f32"].astype(np.float64)
+    d_hip = y[:, 1] - y[:, 0]
+    b_d = parity.bf16_max_err(d_ref.size, float(m["margin_rms"]))
+    e_d = float(np.abs(d_hip - d_ref).max())
+    # (3), (4) flips
+    flip = (d_hip > 0) != (d_ref > 0)
+    worst_flip = float(np.abs(d_ref[flip]).max()) if flip.any() else 0.0
+    exp_n, exp_sd = parity.bf16_expected_flips(d_ref, parity.bf16_sigma_rel() * float(m["margin_rms"]))
+    print("bf16 tensors, S=572: logits err %.3g (bound %.3g; %.2e of |y|max), margin err %.3g (bound %.3g), %d of %d argmax pixels differ, "
+          "largest fp64 margin among them %.3g (bound %.3g), model expects %.0f +- %.0f flips"
+          % (e_log, b_log, e_log / float(m["logits_absmax"]), e_d, b_d, int(flip.sum()), flip.size, worst_flip, b_d, exp_n, exp_sd))
+    assert e_log <= b_log
+    assert e_d <= b_d
+    assert worst_flip <= b_d
+    assert int(flip.sum()) <= exp_n + 4 * exp_sd

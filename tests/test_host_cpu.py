@@ -168,8 +168,15 @@ def test_bench_line_is_short_and_keeps_the_contract_fields():
     full = json.load(open(os.path.join(ROOT, "profiles", "r02_e_bench.json")))
     full["cpu_baseline"].update({"gflops": 790.0, "iters": 5, "s_per_iter": 1.1,
                                  "logits_parity": {"max_abs_err_over_max_abs_ref": 2.1e-6, "bound": 1e-3, "ok": True}})
-    full["comm"] = {"gradient_allreduce": "rccl", "ranks": 8, "rccl_version": 22204, "message_mb": 124.1, "buckets": 6}
+    full["comm"] = {"gradient_allreduce": "rccl", "ranks": 8, "rccl_version": 22204, "message_mb": 124.1, "buckets": 6,
+                    "self_launched": True, "allreduce_ms_per_step": 1.234567, "exposed_ms_per_step": 0.123456}
+    full["roofline"]["traffic_source"] = bench.pmc_traffic(3, "wino", 8)[1] + " " * 0
+    full["bf16"] = {"ms_per_step": 9.56123456, "tiles_per_s": 836.7123456, "steps": 10, "warmup": 3, "kernel": "igemmb+convb64", "frac": 0.3612345,
+                    "peak": 2500.0, "logits_err": 0.0181234, "argmax_flips": 39, "px": 150544, "what": "x" * 400, "parity_note": "y" * 300}
     line, detail = bench.split_line(full, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(line["bf16"])) <= 300 and "what" not in line["bf16"]
+    for k in ("ms_per_step", "tiles_per_s", "frac", "logits_err", "argmax_flips"):
+        assert k in line["bf16"], k
     text = json.dumps(line)
     assert len(text) < bench.LINE_LIMIT <= 4096, len(text)
     back = json.loads(text)
@@ -239,6 +246,86 @@ def test_bench_launcher_relays_rank0_line_and_exit_codes(tmp_path):
     assert bad.returncode == 7 and bad.stdout.strip() == "" and __import__("time").time() - t0 < 30
 
 
+def test_bench_launcher_restarts_the_ranks_with_comm_torch_after_a_hung_rccl_bring_up(tmp_path):
+    """First contact with N GPUs cannot be rehearsed, so its failure mode is: a rank whose unet_dp_init does not return within
+    BENCH_DP_INIT_TIMEOUT ends itself with exit code 3 (bench._call_with_watchdog, here with a stand-in that sleeps for ever);
+    the launcher - a parent that never touched a GPU - stops the other ranks and starts all of them ONCE more, as fresh
+    processes, with `--comm torch`; a second failure is final."""
+    import json
+    import bench
+    # (a) the watchdog itself, in a process of its own (it ends the process)
+    probe = os.path.join(tmp_path, "probe.py")
+    with open(probe, "w") as f:
+        f.write("import sys, time; sys.path.insert(0, %r)\nimport bench\n"
+                "print(bench._call_with_watchdog(lambda: 41 + 1, 5, 'quick call'))\n"
+                "try:\n    bench._call_with_watchdog(lambda: 1 / 0, 5, 'raising call')\nexcept ZeroDivisionError:\n    print('raised')\n"
+                "sys.stdout.flush()\n"
+                "bench._call_with_watchdog(lambda: time.sleep(600), 0.5, 'unet_dp_init stand-in')\nprint('not reached')\n" % ROOT)
+    t0 = __import__("time").time()
+    r = subprocess.run([sys.executable, probe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == bench.EXIT_DP_INIT_TIMEOUT and r.stdout.split() == ["42", "raised"], (r.returncode, r.stdout, r.stderr)
+    assert "unet_dp_init stand-in has not returned" in r.stderr and __import__("time").time() - t0 < 30
+    # (b) the launcher: children hang in "rccl" mode (rank 1 reports it with code 3), succeed once relaunched with --comm torch
+    child = os.path.join(tmp_path, "child.py")
+    with open(child, "w") as f:
+        f.write("import os, sys, time, json\n"
+                "r = int(os.environ['RANK']); args = sys.argv[1:]\n"
+                "open(os.path.join(%r, 'seen_%%d_%%s' %% (r, 'torch' if 'torch' in args else 'rccl')), 'w').write(os.environ['MASTER_PORT'])\n"
+                "if 'torch' not in args:\n"
+                "    if r == 1: time.sleep(0.3); sys.exit(3)\n"
+                "    time.sleep(600)\n"
+                "if 'always-hang' in args:\n"
+                "    sys.exit(3)\n"
+                "if r == 0: print(json.dumps({'metric': 'm', 'value': 2.5, 'comm': args}))\n" % str(tmp_path))
+    runner = os.path.join(tmp_path, "run.py")
+    with open(runner, "w") as f:
+        f.write("import sys; sys.path.insert(0, %r)\nimport bench\n"
+                "real = bench.child_specs\n"
+                "def specs(args, argv, port=None):\n"
+                "    return [([sys.executable, %r] + argv[len(argv) - argv[::-1].index('--') if '--' in argv else 0:], e) for _, e in real(args, argv, port)]\n"
+                "bench.child_specs = specs\n"
+                "argv = ['--gpus', '3'] + sys.argv[1:]\n"
+                "sys.exit(bench.launch(bench.parse_args(['--gpus', '3']), argv))\n" % (ROOT, child))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    ok = subprocess.run([sys.executable, runner, "--", "x"], capture_output=True, text=True, timeout=60, env=env)
+    assert ok.returncode == 0, ok.stderr
+    got = json.loads(ok.stdout.strip())
+    assert got["value"] == 2.5 and got["comm"][-2:] == ["--comm", "torch"]
+    assert "starting the ranks again with --comm torch" in ok.stderr
+    seen = sorted(n for n in os.listdir(tmp_path) if n.startswith("seen_"))
+    assert seen == ["seen_%d_%s" % (r, m) for r in range(3) for m in ("rccl", "torch")]
+    ports = {m: {open(os.path.join(tmp_path, "seen_%d_%s" % (r, m))).read() for r in range(3)} for m in ("rccl", "torch")}
+    assert len(ports["rccl"]) == 1 and len(ports["torch"]) == 1 and ports["rccl"] != ports["torch"]      # one free port per attempt
+    bad = subprocess.run([sys.executable, runner, "--", "always-hang"], capture_output=True, text=True, timeout=60, env=env)
+    assert bad.returncode == 3 and bad.stdout.strip() == ""                                               # only ONE relaunch
+    assert bench._with_comm_torch(["--gpus", "8", "--comm", "rccl", "--steps", "5"]) == ["--gpus", "8", "--steps", "5", "--comm", "torch"]
+    assert bench._with_comm_torch(["--comm=rccl", "--gpus", "2"]) == ["--gpus", "2", "--comm", "torch"]
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_kernels_it_was_measured_on(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json carries the fingerprint of dl-unet_amd/csrc it was measured on (tools/summarize_profiles.py);
+    bench.py gives `traffic: null` (and says why) when the tree's kernels differ, when the batch is not the profiled one, or
+    when no pass exists for the family."""
+    import json
+    import bench
+    sha = bench.csrc_sha()
+    assert len(sha) == 16 and sha == bench.csrc_sha()
+    root = os.path.join(tmp_path, "repo")
+    os.makedirs(os.path.join(root, "profiles"))
+    os.makedirs(os.path.join(root, "dl-unet_amd", "csrc"))
+    open(os.path.join(root, "dl-unet_amd", "csrc", "k.hip"), "w").write("// kernel v1\n")
+    monkeypatch.setattr(bench, "ROOT", root)
+    sha1 = bench.csrc_sha()
+    json.dump({"math3": {"source": "profiles/rXX_pmc_summary.md", "csrc_sha": sha1, "wino_hbm_mb_per_launch": 500.0}},
+              open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"))
+    v, why = bench.pmc_traffic(3, "wino", 8)
+    assert v == 500.0e6 and sha1 in why
+    assert bench.pmc_traffic(3, "wino", 2)[0] is None and bench.pmc_traffic(3, "igemm", 8)[0] is None and bench.pmc_traffic(2, "igemm", 8)[0] is None
+    open(os.path.join(root, "dl-unet_amd", "csrc", "k.hip"), "w").write("// kernel v2\n")
+    v, why = bench.pmc_traffic(3, "wino", 8)
+    assert v is None and "stale" in why
+
+
 def test_bench_tables_from_a_synthetic_launch_dump():
     """bench.layer_table / comm_table on a hand-made per-launch dump: row aggregation, the two roofs, which one binds, SURVEY
     row mapping, per-bucket all-reduce time and the exposed wait."""
@@ -260,3 +347,8 @@ def test_bench_tables_from_a_synthetic_launch_dump():
     cm = bench.comm_table(rows, 2)
     assert abs(cm["allreduce_ms_per_step"] - 0.5) < 1e-12 and abs(cm["exposed_ms_per_step"] - 0.15) < 1e-12
     assert len(cm["buckets"]) == 1 and abs(cm["buckets"][0]["gb_per_s"] - 0.1 / 0.5e-3) < 1e-6
+    # a row above what a streaming copy gets from HBM (0.79 of 8 TB/s) is labelled as partly Infinity-Cache-served
+    fast = dict(rows[2], ms="0.17")
+    assert bench.layer_table([fast], 1, 3)[0]["bound"] == "hbm+mall" and bench.layer_table([rows[2]], 1, 3)[0]["bound"] == "hbm"
+    w = bench.weakest_rows(bench.layer_table([r for r in rows if r["kind"] != "6"], 2, 3), 1)
+    assert w[0]["row"] == "pool1.bwd" and abs(w[0]["frac"] - 0.6) < 1e-9

@@ -70,7 +70,9 @@ def conv_mode(hip, request):
                                      (3, 26, 128, 128), (1, 22, 256, 512), (2, 45, 64, 64),
                                      (1, 66, 512, 512),
                                      # minimal Winograd tile grids (9 x 9, 13 x 13 tiles per image): every 64-tile workgroup crosses an image boundary, ragged last one
-                                     (4, 20, 64, 64), (5, 28, 64, 128)])
+                                     (4, 20, 64, 64), (5, 28, 64, 128),
+                                     # 32 filter rows (the base-32 net of BASELINE configs[4]): half a 64-row block of transformed filters
+                                     (2, 40, 32, 32), (1, 34, 32, 64), (1, 44, 64, 32), (2, 22, 96, 96)])
 def test_conv3x3_fwd(hip, conv_mode, B, H, C, K):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1); w = rnd(K, C, 3, 3, seed=2, scale=0.05); b = rnd(K, seed=3)
@@ -92,7 +94,8 @@ def test_conv3x3_random_shapes(hip):
 
 
 @pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 6, 0, 64, 64, 128),
-                                               (1, 24, 4, 64, 64, 64), (2, 30, -3, 64, 64, 128), (1, 20, 1, 128, 128, 64)])
+                                               (1, 24, 4, 64, 64, 64), (2, 30, -3, 64, 64, 128), (1, 20, 1, 128, 128, 64),
+                                               (1, 26, 5, 32, 32, 32), (2, 32, -2, 32, 32, 32)])
 def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
     keep = Keep()
     """crop_and_concat (network.py:108-127) is never materialised: the conv reads two sources."""
@@ -111,7 +114,8 @@ def test_conv3x3_fwd_virtual_concat(hip, conv_mode, B, Hs, pad, C1, C2, K):
 
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True),
                                                       (2, 13, 128, 256, True, True), (1, 70, 64, 64, True, False), (2, 25, 128, 256, True, True),
-                                                      (1, 66, 512, 512, True, True), (4, 20, 64, 64, True, True)])
+                                                      (1, 66, 512, 512, True, True), (4, 20, 64, 64, True, True),
+                                                      (2, 40, 32, 32, True, True), (1, 34, 32, 64, True, False), (1, 44, 64, 32, False, True)])
 def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = rnd(B, C, H, H, seed=1).requires_grad_(True)
@@ -136,7 +140,8 @@ def test_conv3x3_bwd(hip, conv_mode, B, H, C, K, use_mask, use_add):
     assert nerr(db, dz.sum((0, 2, 3))) < TOL
 
 
-@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 8, 0, 64, 64), (1, 24, 4, 64, 64), (2, 30, -3, 64, 128)])
+@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 8, 0, 64, 64), (1, 24, 4, 64, 64), (2, 30, -3, 64, 128),
+                                          (1, 26, 5, 32, 32), (2, 32, -2, 32, 64)])
 def test_conv3x3_bwd_virtual_concat(hip, conv_mode, B, Hs, pad, C, K):
     keep = Keep()
     H = Hs + 2 * pad

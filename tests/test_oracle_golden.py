@@ -149,3 +149,36 @@ def test_torch_restatement_f64_matches_reference_at_the_baseline_tile(golden_dir
     y.backward(torch.from_numpy(prng.make_cotangent(2, (B, 2, S - 184, S - 184))).double())
     assert nerr(y.detach().numpy()[:, :, ::6, ::6], g["logits_sample_f64"]) < 1e-12
     _checks({k: v.grad.numpy() for k, v in p.items()}, g, "f64", 1e-10)
+
+
+def test_bf16_error_model_against_emulated_storage_roundings(golden_dir):
+    """oracle/parity.py's bf16 error model (sigma_rel = 2^-8 sqrt(43/3), the bound tests/test_bf16_gpu.py holds the HIP path's
+    bf16-tensor mode to at S=572) checked on the CPU against an independent emulation: the fp64 torch restatement with every
+    stored activation and every bf16 filter copy rounded to bf16 (round-to-nearest-even), at S=220 where it takes seconds.
+    The model must be an upper estimate (emulated rms error <= model) without being idle (>= 1/4 of it), and the largest
+    emulated error must respect the Gaussian-tail bound; the margin fixture of the S=572 test must agree with the argmax golden."""
+    from oracle import parity
+    S, B = 220, 2
+    torch.set_num_threads(8)
+    p = torch_ref.params_to_torch(prng.make_params(0), torch.float64)
+    x = torch.from_numpy(prng.make_input(1, B, S)).double()
+    rb = lambda v: v.float().to(torch.bfloat16).double()       # one RNE rounding to 8 significant bits
+    with torch.no_grad():
+        ref = torch_ref.unet_forward(p, x).numpy()
+        emu = torch_ref.unet_forward(p, x, store=rb, wstore=rb).numpy()
+    g = np.load(os.path.join(golden_dir, "unet_S220.npz"))
+    assert nerr(ref, g["logits_f64"]) < 1e-12                    # the un-rounded run is the reference's
+    rms = float(np.sqrt((ref * ref).mean()))
+    e_rms = float(np.sqrt(((emu - ref) ** 2).mean())) / rms
+    e_max = float(np.abs(emu - ref).max())
+    sig = parity.bf16_sigma_rel()
+    print("bf16 storage emulation at S=%d: rms error %.3e of the logits' rms (model %.3e), max %.3g (bound %.3g)"
+          % (S, e_rms, sig, e_max, parity.bf16_max_err(ref.size, rms)))
+    assert 0.25 * sig <= e_rms <= sig
+    assert e_max <= parity.bf16_max_err(ref.size, rms)
+    m = np.load(os.path.join(golden_dir, "unet_S572_margin.npz"))
+    f = np.load(os.path.join(golden_dir, "unet_S572_fwd.npz"))
+    d = m["margin_f64_as_f32"]
+    assert np.array_equal(np.packbits((d > 0).ravel()), f["argmax_packed"])
+    assert abs(float(np.abs(d).min()) - float(f["min_margin"])) < 1e-6 * float(f["min_margin"]) + 1e-7
+    assert abs(float(m["logits_absmax"]) - float(f["logits_norms_f64"][0])) < 1e-9

@@ -54,7 +54,9 @@ for k in sorted(dur, key=lambda k: -dur[k])[:24]:
     for key, sub in DOM:
         if sub in k and not any(e in k for e in EXCL):
             tot_f[key] += 2 * fe[k]["FETCH_SIZE"] / 1024; tot_w[key] += wr[k]["WRITE_SIZE"] / 1024; tot_n[key] += nfe[k]
-out = {"source": "profiles/%s_pmc_summary.md" % tag}
+sys.path.insert(0, os.getcwd())
+import bench as _bench                      # repo root: the same fingerprint bench.py checks before quoting the traffic
+out = {"source": "profiles/%s_pmc_summary.md" % tag, "csrc_sha": _bench.csrc_sha()}
 lines.append("")
 bench_dom = "wino" if "wino" in bench["roofline"]["kernel"] else "igemm" if "igemm" in bench["roofline"]["kernel"] else "wgrad"
 for key, sub in DOM:
@@ -115,5 +117,7 @@ if os.path.exists("profiles/pmc_traffic.json"):
         allm = {}
 allm = {k: v for k, v in allm.items() if k.startswith("math")}
 allm["math" + math_mode] = out
+# The stamp is the fingerprint of dl-unet_amd/csrc at the time THIS script runs: run it on the tree the profile was taken on
+# (right after the gpurun call), before editing any kernel.
 json.dump(allm, open("profiles/pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines[-5:]))
