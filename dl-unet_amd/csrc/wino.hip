@@ -589,9 +589,15 @@ int launch_wino(const IgemmP &p, const float *U, hipStream_t st)
             }
         }
     }
-    // tile order: all n-tiles of an m-tile are neighbours (the workgroups resident together re-read one patch image from L2
-    // instead of 64 different ones from HBM): 0.6-1 % per step against n-major order (UNET_WINO_GN=1), measured round 3
-    static const int gn_env = [] { const char *e = getenv("UNET_WINO_GN"); return e ? atoi(e) : 64; }();
+    // tile order: consecutive slots walk gn n-tiles of one m-tile, then the same n-tiles of the next m-tile (all m-tiles), then
+    // the next group of n-tiles.  The 64 workgroups resident together on an XCD (32 CUs x 2) are then a 16 (m) x 4 (n) block of
+    // the tile grid at about the same K step, and its L2 serves each patch stage to 4 and each U stage to 16 of them.  Round 3
+    // had all n-tiles of an m-tile as neighbours (gn = ntiles: for the >= 512-channel layers 2 m-tiles x 32 n-tiles, i.e. the
+    // whole 37-67 MB of transformed filters re-streamed per pair of m-tiles).  Measured per launch (rocprofv3 FETCH_SIZE x2 +
+    // WRITE_SIZE, tools/wino_gn_pmc.sh; gn = all -> 8 -> 4): 8x30^2x1024->1024 1139 -> 520 -> 462 MB, 8x32^2x512->1024
+    // 583 -> 263 -> 236, 8x56^2x1024->512 1041 -> 730 -> 714, 8x66^2x512->512 651 -> 461 -> 465; launch time unchanged within
+    // 1 % (the counters count L2 misses, most of which the 256 MB Infinity Cache serves: these launches' whole working set fits it)
+    static const int gn_env = [] { const char *e = getenv("UNET_WINO_GN"); return e ? atoi(e) : 4; }();
     q.gn = 1; q.gn_shift = 0;
     while (q.gn * 2 <= gn_env && q.p.ntiles % (q.gn * 2) == 0) { q.gn *= 2; ++q.gn_shift; }
     static bool attr32[64] = {false}, attr32b[64] = {false};
