@@ -42,6 +42,7 @@ _SIGS = {
     "unet_backward_stages": (C.c_int, []),
     "unet_backward_stage": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]),
     "unet_backward_stage_params": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "unet_backward_input": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
     "unet_flops": (C.c_double, [vp, C.c_int, C.c_int, C.c_int]),
     "unet_activation_bytes": (C.c_int, [vp]),
     "unet_debug_buffer": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

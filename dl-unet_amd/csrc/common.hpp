@@ -155,6 +155,7 @@ size_t bias_grad_scratch_bytes(size_t M, int K);
 // HBM-bound layers (direct.hip); es = element size of the activation tensors (4: fp32, 2: bf16)
 int conv1ch_fwd(const float *x, int B, int S, const float *w, const float *bias, int K, void *y, int es, hipStream_t st);
 int conv1ch_bwd(const float *x, int B, int S, int K, const void *dz, float *dw, float *db, float *scratch, int es, hipStream_t st);
+int conv1ch_dgrad(const void *dz, int B, int S, int K, const float *w, float *dx, int es, hipStream_t st);   // d loss / d image
 int head1x1_fwd(const void *x, int B, int H, int W, int C, const float *w, const float *bias, float *logits, int es, hipStream_t st);
 int head1x1_bwd(const void *x, int B, int H, int W, int C, const float *w, const float *dlogits, float dl_scale, void *dz, float *dw,
                 float *db, float *scratch, int es, hipStream_t st);   // every use of dlogits is dlogits * dl_scale (data parallel: 1/world)

@@ -687,6 +687,62 @@ int conv1ch_fwd(const float *x, int B, int S, const float *w, const float *bias,
 }
 
 // rows per workgroup and workgroup count of the weight-gradient pass (<= 1024 partial vectors)
+// conv11c input gradient (only a caller that asks for d loss / d image needs it; the reference's training never does):
+//   dx[b][y][x] = sum_{k,ty,tx} dz[b][y - ty][x - tx][k] w[k][ty][tx]      (full correlation with the flipped filter)
+// One thread per input pixel, the 9 x K filter taps in LDS, dz read with 16-byte (fp32) / 8-byte (bf16) accesses; neighbouring
+// pixels re-read each other's dz rows through L1 / L2.  Not on any timed path.
+template <int K, typename T>
+__global__ __launch_bounds__(256) void conv1ch_dgrad_kernel(const T *__restrict__ dz, const float *__restrict__ w, float *__restrict__ dx, int B, int S)
+{
+    __shared__ float ws[9][K];
+    for (int i = threadIdx.x; i < 9 * K; i += 256) { const int k = i / 9, t = i - 9 * k; ws[t][k] = w[i]; }
+    __syncthreads();
+    const int So = S - 2;
+    const size_t total = (size_t)B * S * S;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int x = (int)(e % S);
+        const int y = (int)((e / S) % S);
+        const int b = (int)(e / ((size_t)S * S));
+        float acc = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int oy = y - ty;
+            if ((unsigned)oy >= (unsigned)So) continue;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int ox = x - tx;
+                if ((unsigned)ox >= (unsigned)So) continue;
+                const T *src = dz + (((size_t)b * So + oy) * So + ox) * K;
+                const float *wt = ws[ty * 3 + tx];
+#pragma unroll
+                for (int k = 0; k < K; k += 4) {
+                    const float4_ v = load4(src + k);
+                    acc += v[0] * wt[k] + v[1] * wt[k + 1] + v[2] * wt[k + 2] + v[3] * wt[k + 3];
+                }
+            }
+        }
+        dx[e] = acc;
+    }
+}
+
+int conv1ch_dgrad(const void *dz, int B, int S, int K, const float *w, float *dx, int es, hipStream_t st)
+{
+    ARG_CHECK(K == 64 || K == 32, "conv1ch: K=%d unsupported (32 or 64)", K);
+    const size_t total = (size_t)B * S * S;
+    const int nb = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    prof_begin(PK_STENCIL, "conv1ch_dgrad", st, 18.0 * (double)B * (S - 2) * (S - 2) * K, 0.0, 4.0 * (double)total + (double)es * B * (S - 2) * (S - 2) * K);
+    if (es == 2) {
+        if (K == 64) hipLaunchKernelGGL((conv1ch_dgrad_kernel<64, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)dz, w, dx, B, S);
+        else hipLaunchKernelGGL((conv1ch_dgrad_kernel<32, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t *)dz, w, dx, B, S);
+    } else {
+        if (K == 64) hipLaunchKernelGGL((conv1ch_dgrad_kernel<64, float>), dim3(nb), dim3(256), 0, st, (const float *)dz, w, dx, B, S);
+        else hipLaunchKernelGGL((conv1ch_dgrad_kernel<32, float>), dim3(nb), dim3(256), 0, st, (const float *)dz, w, dx, B, S);
+    }
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static void conv1ch_bwd_split(int B, int S, int &rpb, int &nb)
 {
     const int nrows = B * (S - 2);

@@ -400,7 +400,7 @@ static int make_plan(Plan &pl, int base, int B, int S, int training, int math)
 extern "C" {
 
 const char *unet_last_error(void) { return g_err; }
-int unet_abi_version(void) { return 3; }
+int unet_abi_version(void) { return 4; }
 
 int unet_set_math(int mode)
 {
@@ -876,6 +876,22 @@ static int backward_stage_body(unet_handle *h, const Plan &pl, int stage, const 
         if ((rc = pool_backward(pl, workspace, l - 1, stream))) return rc;
     }
     return 0;
+}
+
+int unet_backward_input(unet_handle *h, const void *const *params, void *dx, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ARG_CHECK(h && params && dx && workspace, "unet_backward_input: null argument");
+    CHECK_DEVICE(h, "unet_backward_input");
+    Plan pl;
+    if (!h->lookup(workspace, pl)) {
+        set_error("unet_backward_input: no training forward has been run on this workspace");
+        return UNET_E_NOTREADY;
+    }
+    ARG_CHECK(workspace_bytes >= pl.total, "unet_backward_input: workspace too small");
+    MathScope ms(pl.math);
+    RowScope rs(C11C, "dgrad");
+    // g_a1[0] = d loss / d conv11c's output, masked by its ReLU: final once the last backward stage has been enqueued
+    return conv1ch_dgrad(WS(pl.g_a1[0]), pl.B, pl.S, pl.ch[0], PARAM(0), (float *)dx, t_es, (hipStream_t)stream);
 }
 
 int unet_backward(unet_handle *h, const void *const *params, const void *dlogits, void *const *grads,

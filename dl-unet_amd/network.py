@@ -96,7 +96,7 @@ class _UnetFunction(torch.autograd.Function):
             _hip.check(_hip.lib().unet_forward(h.h, ptab, _hip.ptr(x), _hip.ptr(logits), B, S, _hip.ptr(ws), nbytes, 1,
                                                _hip.stream(x.device)), "unet_forward")
         ctx.save_for_backward(*params)
-        ctx.ws, ctx.nbytes, ctx.dev, ctx.module = ws, nbytes, dev, module
+        ctx.ws, ctx.nbytes, ctx.dev, ctx.module, ctx.x_shape = ws, nbytes, dev, module, tuple(x.shape)
         return logits
 
     @staticmethod
@@ -120,8 +120,13 @@ class _UnetFunction(torch.autograd.Function):
                     dp.reduce_stage(buckets, flat, s, h, st)
             if dp is not None:
                 dp.join(h, st)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                # d loss / d image (the reference's callers never ask for it): conv11c's dgrad from the stashed dz
+                dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dlogits.device)
+                _hip.check(L.unet_backward_input(h.h, ptab, _hip.ptr(dx), _hip.ptr(ctx.ws), ctx.nbytes, st), "unet_backward_input")
         ctx.ws = None
-        return (None, None) + tuple(grads)
+        return (dx, None) + tuple(grads)
 
 
 class Unet(nn.Module):
@@ -201,14 +206,12 @@ class Unet(nn.Module):
             raise RuntimeError("Unet.forward: expected input [B,1,S,S], got %s" % (tuple(t.shape),))
         if t.dtype != torch.float32:
             raise RuntimeError("Unet.forward: expected float32 input, got %s" % t.dtype)
-        if t.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the input image is not implemented (conv11c needs no dgrad)")
         t = t.contiguous()
         params = self._params()
         if self._buckets is None:
             order, bounds = _stage_layout()
             self._buckets = dp_mod.GradBuckets([p.numel() for p in params], order, bounds)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if torch.is_grad_enabled() and (t.requires_grad or any(p.requires_grad for p in params)):
             return _UnetFunction.apply(t, self, *params)
         # inference (trainer.py:95 no_grad): no activation-gradient storage
         h = self._get_handle(t.device.index)

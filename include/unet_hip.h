@@ -48,7 +48,7 @@ typedef struct unet_config {
 } unet_config;
 
 const char *unet_last_error(void);
-int unet_abi_version(void);     /* 3.  (2: unet_config::math, unet_dp_*;  3: unet_bce_step, unet_set_grad_scale, unet_set_overlap) */
+int unet_abi_version(void);     /* 4.  (2: unet_config::math, unet_dp_*;  3: unet_bce_step, unet_set_grad_scale, unet_set_overlap;  4: unet_backward_input) */
 
 /* Arithmetic of the dense contractions — the process default, used by the per-op entry points and by handles created
  * with math = -1 (read when a forward is planned; its backward keeps that forward's mode):
@@ -111,6 +111,10 @@ int unet_backward_stages(void);
 int unet_backward_stage(unet_handle *h, int stage, const void *const *params,
                         const void *dlogits, void *const *grads, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* replaces: the gradient autograd returns for the input image when a caller asks for it (t.requires_grad; the reference's
+ * trainer / tester never do: trainer.py:58, tester.py:27 - conv11c's dgrad is the one backward op of network.py:131 they skip).
+ *   dx : [B,1,S,S] fp32, OVERWRITTEN.  Call after the LAST backward stage of the same forward has been enqueued on `stream`. */
+int unet_backward_input(unet_handle *h, const void *const *params, void *dx, void *workspace, size_t workspace_bytes, void *stream);
 /* writes up to cap parameter indices completed by `stage`; returns how many */
 int unet_backward_stage_params(int stage, int *idx, int cap);
 

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libunet_hip.so does not export %s" % name
     assert sorted(_hip.EXPORTS) == declared          # the ctypes table covers the whole header
-    assert L.unet_abi_version() == 3
+    assert L.unet_abi_version() == 4
 
 
 def test_size_contract_no_gpu_needed():

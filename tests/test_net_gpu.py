@@ -182,6 +182,42 @@ def test_full_size_vs_torch_restatement(net):
     assert nerr(grads["finalconv.bias"], g["grad_full_finalconv.bias_f64"]) < 2e-5
 
 
+def test_gradient_with_respect_to_the_input_image(net):
+    """Unet.forward of an input that requires grad (the reference supports it through autograd; its trainer / tester never ask):
+    conv11c's dgrad (unet_backward_input) against the fp64 torch restatement.  S = 188, where the HIP forward takes the fp64
+    branch at every ReLU / pool (test_free_running_gradients...: 0 decisions differ), so the two gradients are comparable
+    directly; the parameter gradients of the same backward must not change."""
+    from oracle import prng, torch_ref
+    S, B = 188, 2
+    x = torch.from_numpy(prng.make_input(1, B, S))
+    dl = torch.from_numpy(prng.make_cotangent(2, (B, 2, S - 184, S - 184)))
+    p64 = torch_ref.params_to_torch(prng.make_params(0), torch.float64)
+    x64 = x.double().requires_grad_(True)
+    torch_ref.unet_forward(p64, x64).backward(dl.double())
+    ref = x64.grad.numpy()
+    net.zero_grad(set_to_none=True)
+    y0 = net(x.cuda())
+    y0.backward(dl.cuda())
+    g0 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    y.backward(dl.cuda())
+    assert xg.grad is not None and xg.grad.shape == xg.shape
+    assert nerr(xg.grad.cpu().numpy(), ref) < GRAD_TOL, nerr(xg.grad.cpu().numpy(), ref)
+    assert torch.equal(y, y0) and all(torch.equal(a, p.grad) for a, p in zip(g0, net.parameters()))
+    # frozen parameters, only the image asks for a gradient
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    try:
+        xg2 = x.cuda().requires_grad_(True)
+        net(xg2).backward(dl.cuda())
+        assert torch.equal(xg2.grad, xg.grad)
+    finally:
+        for p_ in net.parameters():
+            p_.requires_grad_(True)
+
+
 def test_bad_sizes_raise_like_the_reference(net):
     # odd size difference in crop_and_concat -> torch.cat raises in the reference (Q7)
     for S in (570, 200, 187, 60):
