@@ -35,6 +35,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PWMAX = 32;     // pixels per strip (MFMA K = pixel pairs)
 
+__device__ __forceinline__ int fdiv_u(int n, const FastDiv &f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift); }
+
 struct WgradK {               // kernel-side copy with the derived decomposition
     WgradP p;
     int pw, nstrips, rows_per_chunk, nchunks, ntile_i, ntile_j;
@@ -42,6 +44,9 @@ struct WgradK {               // kernel-side copy with the derived decomposition
     int ci_real, cj_real;              // channel counts of the tensors; p.Ci / p.Cj are these rounded up to whole 64-channel tiles
     int nparts, ngroups;               // pixel partitions, and workgroups per channel tile that share them
     size_t pstride;                    // floats per partition in the slab: T*Ci*Cj weights + Cj bias partials
+    // pixel-linear up-conv form (wgrad_up_kernel): Y pixels in total, 64-/32-pixel chunks in total and per workgroup
+    int up_npix, up_nchunks, up_per;
+    FastDiv d_yw;
 };
 
 template <int TY, int TX, int S>
@@ -561,6 +566,186 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
             dst4[(t * 4 + rq) * 64] = f32x4{acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Up-conv weight gradient (2x2 taps, stride 2; network.py:38-53), PIXEL-LINEAR: the taps of a stride-2 transposed convolution
+// do not overlap, so there is no halo and no reason to walk image rows: the reduction runs over the layer-input pixels
+// p = (image, y, x) in plain linear order, in chunks of 64 (bf16) / 32 (fp32) consecutive pixels that cross row and image
+// boundaries freely.  The row-walking kernels above stage a strip of one row per barrier - for the 28 ... 196-pixel rows of
+// the up-convs that is 2 ... 4 MFMA k-steps per tap between barriers with bf16 tensors (MFMA busy 0.12, round 3) and a ragged
+// last strip per row in fp32 (0.53-0.56).  Here every chunk is full: per chunk a workgroup stages [4 taps][PIX][64 co] of
+// dOut (gathered: pixel (2y + ty, 2x + tx)) and [PIX][64 ci] of the layer input by LDS-DMA (40 KiB, two stages), and every
+// wave runs 4 taps x PIX / (16 | 2) MFMAs on its 32 (co) x 32 (ci) block.  Same channel tile per workgroup (64 x 64, all four
+// taps), same LDS images and fragment reads (ds_read_b64_tr_b16 / ds_read_b32), same slab format, bias partial (db = sum of
+// the dOut fragments) and reduce as the kernels above; a workgroup owns a contiguous range of chunks.
+template <bool BF>
+struct UpGeom {
+    static constexpr int ES = BF ? 2 : 4;
+    static constexpr int PIX = BF ? 64 : 32;              // pixels per chunk
+    static constexpr int ROWB = 64 * ES;                  // bytes of a pixel's 64 channels
+    static constexpr int IMG = PIX * ROWB;                // 8 KiB: one tap's (or Y's) pixels of a chunk
+    static constexpr int STAGE = 5 * IMG;                 // X taps 0..3, then Y
+    static constexpr int LDS = 2 * STAGE;                 // 80 KiB: two workgroups per CU
+    static constexpr int PPI = 1024 / ROWB;               // pixels per 1-KiB LDS-DMA instruction: 8 (bf16) / 4 (fp32)
+    static constexpr int NG = PIX / PPI;                  // instructions per image: 8
+    static_assert(NG == 8, "a wave stages pixel groups w and w + 4 of all five images");
+};
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void wgrad_up_kernel(const WgradK k)
+{
+    using G = UpGeom<BF>;
+    constexpr int T = 4, ES = G::ES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const WgradP &p = k.p;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int ntile = k.ntile_i * k.ntile_j;
+    const int grp = logical / ntile;
+    const int tile = logical - grp * ntile;
+    const int it = tile / k.ntile_j, jt = tile - it * k.ntile_j;
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // db[co] = sum of dOut over all pixels: every dOut pixel is staged exactly once (stride == taps); the jt == 0 workgroups sum it
+    const bool do_xbias = p.db != nullptr && jt == 0 && (BF ? wj == 0 : true);
+    float bsum = 0.f;
+
+    // ---- DMA role: pixel (lane / lanes-per-pixel) of an instruction's PPI pixels, 16-byte piece of its 64 channels
+    const int d_px = BF ? lane >> 3 : lane >> 4;
+    const int d_ch = BF ? (((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 8) : 4 * (lane & 15);        // source channel (bf16: swizzled chunk)
+    const bool x_ch_ok = it * 64 + d_ch < k.ci_real, y_ch_ok = jt * 64 + d_ch < k.cj_real;
+    const int x_lane = (p.xc0 + it * 64 + d_ch) * ES, y_lane = (p.yc0 + jt * 64 + d_ch) * ES;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.X, 0, k.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)p.Y, 0, k.ybytes, 0x00020000);
+    static constexpr int OOB = (int)0x80000000;
+    const int YW = p.YW;
+    // tap (ty, tx) of dOut pixel (2y + ty, 2x + tx): a uniform byte offset from tap (0, 0)
+    int tap_off[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) tap_off[t] = ((t >> 1) * p.XW + (t & 1)) * p.XC * ES;
+
+    // stage chunk c into buffer buf: this wave's pixel groups g = wave, wave + 4 of all five images; one division per group
+    auto stage = [&](int c, int buf) {
+        unsigned char *sb = smem + buf * G::STAGE;
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int g = wave + 4 * gg;
+            const int pix = c * G::PIX + g * G::PPI + d_px;
+            const bool ok = pix < k.up_npix;
+            const int r = fdiv_u(pix, k.d_yw);                 // (image, y) row index of the layer input
+            const int x = pix - r * YW;
+            const int xo = ok && x_ch_ok ? ((4 * r * YW + 2 * x) * p.XC) * ES + x_lane : OOB;      // dOut pixel (2y, 2x)
+            const int yo = ok && y_ch_ok ? pix * p.YC * ES + y_lane : OOB;
+#pragma unroll
+            for (int t = 0; t < T; ++t) wg_dma16(rs_x, sb + t * G::IMG + g * 1024, xo, tap_off[t]);
+            wg_dma16(rs_y, sb + 4 * G::IMG + g * 1024, yo, 0);
+        }
+    };
+
+    const int c0 = grp * k.up_per;
+    int c1 = c0 + k.up_per;
+    c1 = c1 < k.up_nchunks ? c1 : k.up_nchunks;
+
+    if constexpr (BF) {
+        // fragment-read role (as wgrad_bf16_kernel): lane = 16 g + 4 q + pp
+        const int f_q = (lane >> 2) & 3, f_pp = lane & 3, f_mh = (lane >> 4) & 1, f_h = lane >> 5;
+        const int cA = wi * 4 + f_mh * 2 + (f_pp >> 1), cB = wj * 4 + f_mh * 2 + (f_pp >> 1);
+        const int sw = ((f_q >> 1) & 1) << 2;
+        const int xoff = (8 * f_h + f_q) * 128 + ((cA ^ sw) * 16) + (f_pp & 1) * 8;
+        const int yoff = 4 * G::IMG + (8 * f_h + f_q) * 128 + ((cB ^ sw) * 16) + (f_pp & 1) * 8;
+        if (c0 < c1) {
+            stage(c0, 0);
+            __syncthreads();
+            for (int c = c0; c < c1; ++c) {
+                const int cur = (c - c0) & 1;
+                if (c + 1 < c1) stage(c + 1, cur ^ 1);
+                const unsigned char *sb = smem + cur * G::STAGE;
+                bf16x8 a[T], b;
+                b = tr_frag(sb + yoff);
+#pragma unroll
+                for (int t = 0; t < T; ++t) a[t] = tr_frag(sb + t * G::IMG + xoff);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kn = (ks + 1 < 4 ? ks + 1 : ks) * (16 * 128);
+                    const bf16x8 bn = tr_frag(sb + yoff + kn);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if (do_xbias) bsum += frag_sum(a[t]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b, acc[t], 0, 0, 0);
+                        a[t] = tr_frag(sb + t * G::IMG + xoff + kn);
+                        __builtin_amdgcn_sched_barrier(0);      // keep the refill BEHIND its MFMA
+                    }
+                    b = bn;
+                }
+                __syncthreads();        // the next chunk has landed (vmcnt(0)); every wave is done with this buffer
+            }
+        }
+    } else {
+        const int l31 = lane & 31, lh = lane >> 5;
+        const int a_lane = (wi * 32 + l31) * 4, b_lane = 4 * G::IMG + (wj * 32 + l31) * 4;
+        const int bch = tid & 63, bpg = tid >> 6;
+        if (c0 < c1) {
+            stage(c0, 0);
+            __syncthreads();
+            for (int c = c0; c < c1; ++c) {
+                const int cur = (c - c0) & 1;
+                if (c + 1 < c1) stage(c + 1, cur ^ 1);
+                const unsigned char *sb = smem + cur * G::STAGE;
+                if (do_xbias) {
+                    const float *xb_ = (const float *)sb + bch;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        for (int px = bpg; px < G::PIX; px += 4) bsum += xb_[(t * G::PIX + px) * 64];
+                }
+#pragma unroll 4
+                for (int q = 0; q < G::PIX / 2; ++q) {
+                    const int pix = 2 * q + lh;
+                    const float b = *(const float *)(sb + b_lane + pix * 256);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const float a = *(const float *)(sb + t * G::IMG + a_lane + pix * 256);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // slab of this group: the weight partials in register order, then the bias partials (formats of the kernels above)
+    float *slab = p.slab + (size_t)grp * k.pstride;
+    if constexpr (BF) {
+        if (do_xbias) {
+            const float v = bsum + __shfl_xor(bsum, 32, 64);
+            if (lane < 32) slab[(size_t)T * p.Ci * p.Cj + it * 64 + wi * 32 + lane] = v;
+        }
+    } else {
+        if (do_xbias) {
+            float *red = (float *)smem;             // all LDS reads of the loop are behind its last barrier
+            red[tid] = bsum;
+            __syncthreads();
+            if (tid < 64) slab[(size_t)T * p.Ci * p.Cj + it * 64 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+        }
+    }
+    f32x4 *dst4 = (f32x4 *)(slab + ((size_t)(tile * 4 + wave) * T) * 1024) + lane;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            dst4[(t * 4 + rq) * 64] = f32x4{acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]};
+}
+
 // out[i*si + j*sj + t*st] = sum_P slab_P(t,i,j)  and  db[j] = sum_P slab[P][T*Ci*Cj + j], in a fixed order.
 // Workgroup = 64 consecutive outputs x 4 partition groups (combined through LDS): enough loads in flight
 // even when the output is tiny (64x64x9) and the partition count is in the thousands.
@@ -687,6 +872,53 @@ static void decompose(const WgradP &p, WgradK &k)
     k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + (p.Ci > p.Cj ? p.Ci : p.Cj), 64);
 }
 
+// the pixel-linear up-conv form: the full-window 2x2 stride-2 weight gradient with its bias gradient on X (or none), tensors
+// below 2 GiB (buffer descriptors), exact fp32 or bf16 tensors (the bf16x3 split keeps the row-walking kernel)
+static bool up_applicable(const WgradP &p)
+{
+    static const int on = [] { const char *e = getenv("UNET_WGRAD_UP"); return e ? atoi(e) : 1; }();      // 0: the row-walking kernels (A/B)
+    if (!on || p.TY != 2 || p.TX != 2 || p.stride != 2 || p.xpad != 0 || p.oy0 != 0 || p.ox0 != 0) return false;
+    if (p.math == 1 || (p.db && !p.db_on_x)) return false;
+    if (p.ywin0 != 0 || p.xwin0 != 0 || p.ywin1 != p.YH || p.xwin1 != p.YW || p.XH != 2 * p.YH || p.XW != 2 * p.YW) return false;
+    const size_t es = p.math == 2 ? 2 : 4;
+    return (size_t)p.NB * p.XH * p.XW * p.XC * es < 0x7FFFFFFFull && (size_t)p.NB * p.YH * p.YW * p.YC * es < 0x7FFFFFFFull && get_lds_dma_mode() != 0;
+}
+
+static void up_decompose(const WgradP &p, WgradK &k)
+{
+    const int pix = p.math == 2 ? 64 : 32;
+    k.ntile_i = p.Ci / 64; k.ntile_j = p.Cj / 64;
+    k.up_npix = p.NB * p.YH * p.YW;
+    k.up_nchunks = cdiv(k.up_npix, pix);
+    const int ntile = k.ntile_i * k.ntile_j;
+    int g = 512 / ntile;                        // two workgroups per CU (80 KiB of LDS each)
+    if (g < 1) g = 1;
+    if (g > k.up_nchunks) g = k.up_nchunks;
+    k.up_per = cdiv(k.up_nchunks, g);
+    k.ngroups = cdiv(k.up_nchunks, k.up_per);
+    k.d_yw = make_fastdiv((unsigned)p.YW);
+    k.pstride = align_up((size_t)p.TY * p.TX * p.Ci * p.Cj + (p.Ci > p.Cj ? p.Ci : p.Cj), 64);
+}
+
+template <bool BF>
+static int launch_wgrad_up(WgradK &k, hipStream_t st)
+{
+    using G = UpGeom<BF>;
+    static bool attr_done[64] = {false};
+    auto kern = wgrad_up_kernel<BF>;
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, G::LDS, attr_done)) return rc_;
+    k.xbytes = (int)((size_t)k.p.NB * k.p.XH * k.p.XW * k.p.XC * G::ES);
+    k.ybytes = (int)((size_t)k.p.NB * k.p.YH * k.p.YW * k.p.YC * G::ES);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "wgrad_up<%s> Ci=%d Cj=%d Y=%dx%d chunks=%d per=%d groups=%d", BF ? "bf16" : "f32", k.p.Ci, k.p.Cj, k.p.YH, k.p.YW, k.up_nchunks, k.up_per, k.ngroups);
+    prof_begin(PK_WGRAD, tag, st, wgrad_alg_flops(k.p), 2.0 * (double)k.up_nchunks * G::PIX * 4.0 * k.p.Ci * k.p.Cj,
+               BF ? wgrad_alg_bytes(k.p) / 2.0 + 2.0 * 4.0 * k.p.Ci * k.p.Cj : wgrad_alg_bytes(k.p));
+    hipLaunchKernelGGL(kern, dim3(k.ngroups * k.ntile_i * k.ntile_j), dim3(256), G::LDS, st, k);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // whole 64-channel tiles: the kernels' unit; tensors with 32 channels (base-32 net) occupy half a tile
 static WgradP padded_tiles(const WgradP &p)
 {
@@ -701,7 +933,14 @@ size_t wgrad_slab_need(const WgradP &p0)
     const WgradP p = padded_tiles(p0);
     WgradK k{};
     decompose(p, k);
-    const size_t a = (size_t)k.ngroups * k.pstride * sizeof(float), b = wgradw_slab_need(p);
+    size_t a = (size_t)k.ngroups * k.pstride * sizeof(float);
+    const size_t b = wgradw_slab_need(p);
+    if (p.TY == 2 && p.TX == 2 && p.stride == 2) {           // the pixel-linear up-conv form may use more groups (sized for either)
+        WgradK u{};
+        up_decompose(p, u);
+        const size_t c = (size_t)u.ngroups * u.pstride * sizeof(float);
+        if (c > a) a = c;
+    }
     return a > b ? a : b;
 }
 
@@ -798,7 +1037,8 @@ int launch_wgrad(WgradP p, hipStream_t st)
     if (winograd) return launch_wgradw(p, st);     // Winograd F(3x3 <- 2x2) (wgradw.hip)
     WgradK k{};
     k.p = p;
-    decompose(p, k);
+    const bool up = up_applicable(p);
+    if (up) up_decompose(p, k); else decompose(p, k);
     k.ci_real = ci_real; k.cj_real = cj_real;
     const int nP = k.ngroups;                 // slabs to reduce
     const int T = p.TY * p.TX;
@@ -806,7 +1046,9 @@ int launch_wgrad(WgradP p, hipStream_t st)
     ARG_CHECK(need <= p.slab_bytes, "wgrad: slab scratch too small (%zu < %zu)", p.slab_bytes, need);
     int rc;
     const int mode = p.math == 3 ? 0 : p.math;     // mode 3 (Winograd) falls back to the exact fp32 kernel for the shapes wgradw.hip does not take
-    if (p.TY == 3 && p.TX == 3 && p.stride == 1)
+    if (up)
+        rc = mode == 2 ? launch_wgrad_up<true>(k, st) : launch_wgrad_up<false>(k, st);
+    else if (p.TY == 3 && p.TX == 3 && p.stride == 1)
         rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_b<3, 3, 1>(k, st);
     else if (p.TY == 2 && p.TX == 2 && p.stride == 2)
         rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_b<2, 2, 2>(k, st);
