@@ -31,6 +31,31 @@ def maybe_mkdir_p(path):
     os.makedirs(path, exist_ok=True)
 
 
+_PROGRESS_FILES = (('train_iou', 'train_eval_iou.out'), ('train_pe', 'train_eval_pe.out'), ('val_iou', 'val_eval_iou.out'),
+                   ('val_pe', 'val_eval_pe.out'), ('loss', 'loss.out'), ('loss_val', 'loss_val.out'))
+
+
+def _f6(v):
+    return "{:.6f}".format(v)
+
+
+def _report(rows):
+    """The epoch summary on stdout, label column 27 wide as in the reference's prints (trainer.py:150-160)."""
+    for label, text in rows:
+        print('%-27s %s' % (label, text))
+    print(' ')
+
+
+def _save_weights(unet, fold_dir, tag, before=None):
+    """models/unet_weight_save_<tag>.pth + the reference's two announcement lines (trainer.py:143-147 and its siblings)."""
+    path = os.path.join(fold_dir, 'models', 'unet_weight_save_{}.pth'.format(tag))
+    torch.save(unet.state_dict(), path)
+    if before is not None:
+        print(before)
+    print('Model has been saved:')
+    print(path)
+
+
 def _goal_for(DATASET):
     """(when_to_stop, goal) exactly as the reference's `DATASET is '<literal>'` chain decides it
     (trainer.py:18-27).  Which object a caller can hold: CPython interns identifier-like string
@@ -129,41 +154,27 @@ def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_di
         loss_epoch = total_loss / (len(train_loader) * batch_size)
         loss_epoch_val = total_loss_val / (len(val_loader) * batch_size)
 
-        if loss_epoch_val < (loss_best_epoch * (1.0 - scheduler.threshold)):
+        improved = loss_epoch_val < (loss_best_epoch * (1.0 - scheduler.threshold))
+        if improved:
             loss_best_epoch = loss_epoch_val
             print('New best epoch!')
-            my_patience = 0
-            PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_best.pth')
-            torch.save(unet.state_dict(), PATH)
-            print('Model has been saved:')
-            print(PATH)
-        else:
-            my_patience += 1
+            _save_weights(unet, fold_dir, 'best')
+        my_patience = 0 if improved else my_patience + 1
 
-        print('Current lr is:             ', l_rate)
-        print('Patience is:                {}/{}'.format(my_patience, scheduler.patience))
-        print('Mean IoU training:         ', "{:.6f}".format(train_eval_epoch[0]))
-        print('Mean PE training:          ', "{:.6f}".format(train_eval_epoch[1]))
-        print('Mean IoU validation:       ', "{:.6f}".format(val_eval_epoch[0]))
-        print('Mean PE validation:        ', "{:.6f}".format(val_eval_epoch[1]))
-        print('Total training loss:       ', "{:.6f}".format(loss_epoch.item()))
-        print('Total validation loss:     ', "{:.6f}".format(loss_epoch_val.item()))
-        print('Best epoch validation loss:', "{:.6f}".format(float(loss_best_epoch)))
-        print('Epoch duration:            ', "{:.6f}".format(time() - start), 's')
-        print(' ')
+        _report((('Current lr is:', l_rate),
+                 ('Patience is:', '{}/{}'.format(my_patience, scheduler.patience)),
+                 ('Mean IoU training:', _f6(train_eval_epoch[0])), ('Mean PE training:', _f6(train_eval_epoch[1])),
+                 ('Mean IoU validation:', _f6(val_eval_epoch[0])), ('Mean PE validation:', _f6(val_eval_epoch[1])),
+                 ('Total training loss:', _f6(loss_epoch.item())), ('Total validation loss:', _f6(loss_epoch_val.item())),
+                 ('Best epoch validation loss:', _f6(float(loss_best_epoch))),
+                 ('Epoch duration:', _f6(time() - start) + ' s')))
 
-        # progress series, same six files as the reference (trainer.py:178-183)
+        # the six progress series, one value per epoch, rewritten whole every epoch (trainer.py:162-183)
         new = dict(train_iou=train_eval_epoch[0], train_pe=train_eval_epoch[1], val_iou=val_eval_epoch[0],
                    val_pe=val_eval_epoch[1], loss=loss_epoch.item(), loss_val=loss_epoch_val.item())
-        for k, v in new.items():
-            progress[k] = np.array([v]) if progress[k] is None else np.append(progress[k], [v])
-        pdir = os.path.join(fold_dir, 'progress')
-        np.savetxt(os.path.join(pdir, 'train_eval_iou.out'), progress['train_iou'])
-        np.savetxt(os.path.join(pdir, 'train_eval_pe.out'), progress['train_pe'])
-        np.savetxt(os.path.join(pdir, 'val_eval_iou.out'), progress['val_iou'])
-        np.savetxt(os.path.join(pdir, 'val_eval_pe.out'), progress['val_pe'])
-        np.savetxt(os.path.join(pdir, 'loss.out'), progress['loss'])
-        np.savetxt(os.path.join(pdir, 'loss_val.out'), progress['loss_val'])
+        for k, fname in _PROGRESS_FILES:
+            progress[k] = np.array([new[k]]) if progress[k] is None else np.append(progress[k], [new[k]])
+            np.savetxt(os.path.join(fold_dir, 'progress', fname), progress[k])
 
         if save_optimizer:
             import checkpoint
@@ -179,31 +190,21 @@ def training(unet, train_loader, val_loader, epochs, batch_size, device, fold_di
         if when_to_stop is not None:
             # goal armed (trainer.py:185-214): the periodic checkpoint and the LR-floor stop are skipped this epoch
             if val_eval_epoch[0] > goal:
-                PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_{}.pth'.format(DATASET))
-                torch.save(unet.state_dict(), PATH)
-                print('The goal was reached in epoch {}!'.format(epoch))
-                print('Model has been saved:')
-                print(PATH)
+                _save_weights(unet, fold_dir, DATASET, before='The goal was reached in epoch {}!'.format(epoch))
                 when_to_stop = None
             continue
 
         if epoch % 25 == 0:
-            PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_latest.pth')
-            torch.save(unet.state_dict(), PATH)
-            print('Model has been saved:')
-            print(PATH)
+            _save_weights(unet, fold_dir, 'latest')
 
-        if l_rate < 10 * scheduler.eps and my_patience == scheduler.patience:
-            print(f'LR dropped below {10 * scheduler.eps}!')
-            print('Stopping training')
-            print(' ')
-            PATH = os.path.join(fold_dir, 'models', 'unet_weight_save_latest.pth')
-            torch.save(unet.state_dict(), PATH)
-            print('Model has been saved:')
-            print(PATH)
+        lr_floor = 10 * scheduler.eps
+        out_of_patience = my_patience == scheduler.patience
+        if l_rate < lr_floor and out_of_patience:
+            for line in (f'LR dropped below {lr_floor}!', 'Stopping training', ' '):
+                print(line)
+            _save_weights(unet, fold_dir, 'latest')
             break
-
-        if my_patience == scheduler.patience:
+        if out_of_patience:
             my_patience = -1
 
     print('Training is finished as epoch {} has been reached'.format(epoch))
