@@ -28,37 +28,32 @@ def save_image(tensor, path):
 
 
 def testing(unet, test_loader, batch_size, device, output_dir):
-    start = time()
-    test_eval = None
-    idx = 0
+    t0 = time()
+    for sub in ('images', 'preds', 'labels'):
+        maybe_mkdir_p(os.path.join(output_dir, sub))
+    first = None                      # Q5: the reference keeps only the first sample's metrics
 
-    maybe_mkdir_p(os.path.join(output_dir, 'images'))
-    maybe_mkdir_p(os.path.join(output_dir, 'preds'))
-    maybe_mkdir_p(os.path.join(output_dir, 'labels'))
-
-    for image, label in test_loader:
+    for n, (image, label) in enumerate(test_loader):
         with torch.no_grad():      # the reference leaves autograd on here (Q8); only memory differs
-            pred = unet(image.to(device))
-        pad = int((pred.shape[-1] - label.shape[-1]) / 2)
+            logits = unet(image.to(device))
+        side = label.shape[-1]
+        off = int((logits.shape[-1] - side) / 2)
         # crop + argmax + IoU / pixel-error counts in one pass on the device (no per-image mask download)
-        pred, stats = hip_optim.crop_argmax_metrics(pred, label)
+        mask, stats = hip_optim.crop_argmax_metrics(logits, label)
+        for sub, stem, t in (('images', 'image', image[0, 0, off:side + off, off:side + off]),
+                             ('labels', 'label', label[0, 0].float()),
+                             ('preds', 'pred', mask[0].float())):
+            save_image(t, os.path.join(output_dir, sub, '%s%d.tif' % (stem, n)))
+        if first is None:
+            inter, union, diff = (int(v) for v in stats[0].tolist())
+            first = metrics_from_counts(inter, union, diff, side * label.shape[-2])
 
-        save_image(image[0, 0, pad:label.shape[-1] + pad, pad:label.shape[-1] + pad], os.path.join(output_dir, 'images', f'image{idx}.tif'))
-        save_image(label[0, 0, :, :].float(), os.path.join(output_dir, 'labels', f'label{idx}.tif'))
-        save_image(pred[0, :, :].float(), os.path.join(output_dir, 'preds', f'pred{idx}.tif'))
-        idx += 1
+    mean, std = np.mean(first, axis=1), np.std(first, axis=1)
+    for k, fname in enumerate(('test_iou.out', 'test_pe.out')):
+        np.savetxt(os.path.join(output_dir, fname), [mean[k], std[k]])
 
-        if test_eval is None:      # Q5: the reference keeps only the first sample's metrics
-            inter, union, diff = [int(v) for v in stats[0].tolist()]
-            test_eval = metrics_from_counts(inter, union, diff, label.shape[-1] * label.shape[-2])
-
-    test = np.mean(test_eval, axis=1)
-    test_std = np.std(test_eval, axis=1)
-    np.savetxt(os.path.join(output_dir, 'test_iou.out'), [test[0], test_std[0]])
-    np.savetxt(os.path.join(output_dir, 'test_pe.out'), [test[1], test_std[1]])
-
-    print('Mean IoU testing:', "{:.6f}".format(test[0]))
-    print('Mean PE testing :', "{:.6f}".format(test[1]))
-    print('Testing took    :', "{:.6f}".format(time() - start), 's')
+    for label_, value in (('Mean IoU testing:', mean[0]), ('Mean PE testing :', mean[1])):
+        print(label_, "{:.6f}".format(value))
+    print('Testing took    :', "{:.6f}".format(time() - t0), 's')
     print(' ')
     print('Testing is finished')
