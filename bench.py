@@ -756,7 +756,9 @@ def run_rank(args):
         if rank == 0:
             blk = {"ms_per_step": dtb / nb * 1e3, "tiles_per_s": B * world * nb / dtb, "steps": nb, "warmup": 3,
                    "what": "the step above with bf16 tensors (unet_set_math(2): bf16 activations / activation gradients / packed filters, "
-                           "fp32 accumulation, parameters, gradients and all-reduce), timed like the main region; not part of `value`"}
+                           "fp32 accumulation, parameters, gradients and all-reduce), timed like the main region; not part of `value`.  With bf16 "
+                           "tensors the weight gradients run on the handle's auxiliary stream next to the dgrad chain (unet_set_overlap default); "
+                           "`frac` comes from the region's last two steps, which carry per-launch events and therefore run on one stream"}
             if st_b is not None and st_b[0] > 0:
                 blk.update({"kernel": "igemmb+convb64", "frac": st_b[3] / (st_b[0] * 1e-3) / 1e12 / PEAK_TFLOPS[2], "peak": PEAK_TFLOPS[2],
                             "avg_launch_ms": st_b[0] / max(st_b[1], 1), "launches_per_step": st_b[1] / ns_b,

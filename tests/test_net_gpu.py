@@ -484,6 +484,39 @@ def test_bf16_compute_mode(math_mode):
     assert max(r["grads"].values()) < 6e-2
 
 
+def test_bf16_tensors_overlap_default_is_bit_identical_to_one_stream(math_mode):
+    """With bf16 tensors the weight gradients run on the handle's auxiliary stream by default (unet_set_overlap(-1): per
+    arithmetic mode).  Same kernels on the same data: logits and all 46 gradients must be bit-identical to the one-stream
+    order, run after run."""
+    import _hip
+    import network
+    from oracle import prng
+    L = _hip.lib()
+    math_mode(2)
+    m = network.Unet()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in prng.make_params(0).items()})
+    m = m.to("cuda:0")
+    x = torch.from_numpy(prng.make_input(1, 2, 380)).cuda()
+    dl = torch.from_numpy(prng.make_cotangent(2, (2, 2, 196, 196))).cuda()
+
+    def once():
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        y.backward(dl)
+        torch.cuda.synchronize()
+        return y.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+    try:
+        _hip.check(L.unet_set_overlap(0), "unet_set_overlap")
+        y0, g0 = once()
+        _hip.check(L.unet_set_overlap(-1), "unet_set_overlap")
+        for _ in range(3):
+            y1, g1 = once()
+            assert torch.equal(y0, y1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    finally:
+        _hip.check(L.unet_set_overlap(-1), "unet_set_overlap")
+
+
 @pytest.mark.parametrize("B,S", [(1, 188), (3, 252), (2, 700), (5, 380), (1, 1212), (16, 572)])
 def test_shape_sweep_forward_backward(net, B, S):
     """Sizes of the BASELINE configs and ragged batches: finite results, gradients of a batch equal the sum of the
@@ -520,6 +553,7 @@ def test_overlap_knob_gives_bit_identical_gradients(net):
         torch.cuda.synchronize()
         return y.detach().clone(), [p.grad.clone() for p in net.parameters()]
 
+    _hip.check(L.unet_set_overlap(0), "unet_set_overlap")
     y0, g0 = once()
     _hip.check(L.unet_set_overlap(1), "unet_set_overlap")
     try:
@@ -529,7 +563,7 @@ def test_overlap_knob_gives_bit_identical_gradients(net):
         r = parity.check_same_branch(380, 1)
         assert r["fwd"] < FWD_TOL and max(r["grads"].values()) < GRAD_TOL
     finally:
-        _hip.check(L.unet_set_overlap(0), "unet_set_overlap")
+        _hip.check(L.unet_set_overlap(-1), "unet_set_overlap")       # the default: per arithmetic mode
 
 
 def test_rccl_communicator_behind_the_c_abi_single_rank(net):
