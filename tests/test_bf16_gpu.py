@@ -138,7 +138,7 @@ def test_conv3x3_bwd_virtual_concat_bf16(hip, B, Hs, pad, C, K):
     assert nerr(db, dz.sum((0, 2, 3))) < TOL_F32
 
 
-@pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 4, 1024, 512), (1, 40, 128, 64)])
+@pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 4, 1024, 512), (1, 40, 128, 64), (1, 5, 64, 64), (5, 6, 256, 256)])
 def test_upconv2_fwd_bwd_bf16(hip, B, H, Ci, Co):
     keep = Keep()
     x = bf(rnd(B, Ci, H, H, seed=1).clamp_min(0)).requires_grad_(True)

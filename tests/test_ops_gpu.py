@@ -173,7 +173,9 @@ def test_upconv2_fwd(hip, B, H, Ci, Co):
     assert nerr(nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 18, 128, 64)])
+# (the weight gradient is the pixel-linear kernel: fewer pixels than one 32-pixel chunk, a ragged last chunk, chunks that cross
+#  image boundaries, the half-filled channel tiles of the base-32 net, several channel tiles in both directions)
+@pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 18, 128, 64), (1, 5, 64, 64), (3, 11, 64, 32), (5, 6, 256, 256)])
 def test_upconv2_bwd(hip, B, H, Ci, Co):
     keep = Keep()
     x = rnd(B, Ci, H, H, seed=1).clamp_min(0).requires_grad_(True)     # the producer's ReLU output
