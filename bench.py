@@ -292,8 +292,8 @@ def pmc_traffic(math, family, B):
     if not v:
         return None, "no PMC pass for this family"
     if t.get("csrc_sha") != csrc_sha():
-        return None, "stale: %s was measured on other kernel sources (stamp %s, tree %s); rerun tools/profile_round.sh" % (t.get("source"), t.get("csrc_sha"), csrc_sha())
-    return v * 1e6, "%s: rocprofv3 --pmc passes of this command on these kernel sources (stamp %s), FETCH_SIZE x2 + WRITE_SIZE per launch" % (t.get("source"), t.get("csrc_sha"))
+        return None, "stale: %s was measured on kernel sources %s, this tree is %s; rerun tools/profile_round.sh" % (t.get("source"), t.get("csrc_sha"), csrc_sha())
+    return v * 1e6, "%s (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 + WRITE_SIZE per launch; kernel sources %s = this tree)" % (t.get("source"), t.get("csrc_sha"))
 
 
 def cpu_baseline(budget_s=30.0, gpu_checks=None):
