@@ -1,14 +1,14 @@
 // igemmb.hip — implicit GEMM on the bf16 matrix cores with bf16 tensors in HBM (arithmetic mode 2, BASELINE config #3):
 // activations, their gradients and the packed filters are bf16 (2 B/element), accumulation is fp32
-// (v_mfma_f32_32x32x16_bf16), bias is fp32, the epilogue rounds once to bf16 (RNE).
+// (v_mfma_f32_16x16x32_bf16 here, v_mfma_f32_32x32x16_bf16 in convb64), bias is fp32, the epilogue rounds once to bf16 (RNE).
 //
 // Same contraction family as igemm.hip (conv3x3 fwd / dgrad over the virtual concat, up-conv fwd / dgrad; network.py:131-188
 // and their autograd) and the same descriptor (IgemmP; tensor pointers are bf16 here), but built for the 16x faster pipe:
 //   * operands go HBM -> LDS by LDS-DMA through buffer descriptors, bf16 as stored: no VGPR round trip, no conversion;
 //   * an LDS row is 128 B = 64 channels of one pixel (or 64 K entries of one filter row), 16-byte chunks XOR-swizzled with
-//     (row >> 1) & 7 on the DMA source address and on the fragment read: a ds_read_b128 IS one 32x32x16 operand fragment
-//     (lane (r, h) holds k = 8h .. 8h+7 of row r) and the reads are bank-conflict free;
-//   * K step = 64 channels of one tap (4 MFMA k-steps; taps innermost), double buffered, one barrier per step;
+//     (row >> 1) & 7 on the DMA source address and on the fragment read: a ds_read_b128 IS one 16x16x32 operand fragment
+//     (lane (r, q) holds k = 8q .. 8q+7 of row r of the k32 step) and the reads are bank-conflict free;
+//   * K step = 64 channels of one tap (2 MFMA k-steps; taps innermost), double buffered, one barrier per step;
 //   * epilogue: each wave transposes its 32 x 64 accumulator slabs through LDS and stores 16 bytes per lane (8 channels),
 //     128 contiguous bytes per pixel row, with bias / +add / ReLU (deferred-ReLU window) / ReLU' mask fused.
 // Measured (B = 8 layers of the net, rocprofv3 PMC): MFMA pipe 0.32-0.37 busy, LDS bank-conflict ratio 0.02-0.07, 550-925
@@ -47,8 +47,8 @@ __device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, 
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 
 // ---- epilogue -----------------------------------------------------------------------------------------------------------
-// acc[tm][tn]: 32x32 tiles of the wave's 64x64 block (rows = pixels, columns = output channels; C/D layout: column = lane & 31,
-// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Per tm the wave writes its 32 x 64 slab to a private LDS patch (row pitch 68
+// acc[i][j]: 16x16 tiles of the wave's 64x64 block (rows = pixels, columns = output channels; C/D layout: column = lane & 15,
+// row = 4 (lane >> 4) + r).  Per slab tm (tile rows 2 tm, 2 tm + 1) the wave writes 32 x 64 values to a private LDS patch (row pitch 68
 // floats: 16-B aligned rows, conflict-free b128 read-back) and reads it back as rows: lane -> (row = lane >> 3 + 8k, 8 channels).
 constexpr int EPB_PITCH = 68;
 constexpr int EPB_WAVE_BYTES = 32 * EPB_PITCH * 4;          // 8704
@@ -88,35 +88,7 @@ __device__ __forceinline__ void igemmb_rows_linear(const P &p, int m0, int tid, 
 // PF = row passes whose +add / mask operands are prefetched together (all of a slab's by default; the register-resident-filter
 // kernel below has fewer registers to spare)
 // The accumulators reach the store loop through a writer: write(tm, patch) puts slab tm (32 rows x 32 TN columns, bias added)
-// of the wave's block into the patch.  Acc32: 32x32x16 MFMAs (column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5));
-// Acc16: 16x16x32 MFMAs (column = lane & 15, row = 4 (lane >> 4) + r), two 16-row tiles per slab.
-template <int TN, class P>
-struct Acc32 {
-    f32x16 (&acc)[2][TN];
-    float bv[TN];
-    __device__ __forceinline__ Acc32(const P &p, f32x16 (&a)[2][TN], int n0w, int lane) : acc(a)
-    {
-        const int l31 = lane & 31;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            bv[tn] = 0.f;
-            if (p.bias) {
-                int n = n0w + tn * 32 + l31;
-                n = n < p.Nn ? n : p.Nn - 1;
-                bv[tn] = p.bias[p.cout ? n % p.cout : n];
-            }
-        }
-    }
-    __device__ __forceinline__ void write(int tm, float *patch, int lane) const
-    {
-        const int l31 = lane & 31, lh = lane >> 5;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPB_PITCH + tn * 32 + l31] = acc[tm][tn][r] + bv[tn];
-    }
-};
+// of the wave's block into the patch.  Acc16: 16x16x32 MFMAs (column = lane & 15, row = 4 (lane >> 4) + r), two 16-row tiles per slab.
 template <int TN, class P>
 struct Acc16 {
     f32x4 (&acc)[4][2 * TN];
@@ -147,7 +119,7 @@ struct Acc16 {
     }
 };
 
-template <int TN, int PF = 0, class P = IgemmP, class ACC = Acc32<TN, P>>
+template <int TN, int PF = 0, class P = IgemmP, class ACC = Acc16<TN, P>>
 __device__ __forceinline__ void igemmb_store(const P &p, const ACC &accw, int wrow0, int n0w, int lane, float *patch,
                                              const unsigned *rowoff, const unsigned char *rflag)
 {
@@ -242,20 +214,16 @@ __device__ __forceinline__ void igemmb_epilogue(const P &p, A &acc, int m0, int 
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    if constexpr (sizeof(acc[0][0]) == sizeof(f32x16)) {
-        const Acc32<2, P> w(p, acc, n0 + wn * 64, lane);
-        igemmb_store<2, 0, P>(p, w, wm * 64, n0 + wn * 64, lane, patch0 + wave * (EPB_WAVE_BYTES / 4), rowoff, rflag);
-    } else {
-        const Acc16<2, P> w(p, acc, n0 + wn * 64, lane);
-        igemmb_store<2, 0, P, Acc16<2, P>>(p, w, wm * 64, n0 + wn * 64, lane, patch0 + wave * (EPB_WAVE_BYTES / 4), rowoff, rflag);
-    }
+    const Acc16<2, P> w(p, acc, n0 + wn * 64, lane);
+    igemmb_store<2, 0, P, Acc16<2, P>>(p, w, wm * 64, n0 + wn * 64, lane, patch0 + wave * (EPB_WAVE_BYTES / 4), rowoff, rflag);
 }
 
 // ---- plain kernel: every tap re-stages its A rows (up-conv GEMMs, and any 3x3 shape the halo kernel does not take) -------
-// M16: the products run as v_mfma_f32_16x16x32_bf16 (4 x 4 tiles of 16 x 16 per wave) instead of 32x32x16 (2 x 2 of 32 x 32): the
-// same LDS reads per flop and the same cycles per flop, but under bf16 MFMA load the part holds a higher clock on the 16 x 16
-// shape (MI355X_MICROARCH.md, DVFS give-back item 7); UNET_IGB_MFMA16 = 0 selects the 32 x 32 form for an A/B on one box.
-template <int BM, int BN, bool PAD, bool M16>
+// The products run as v_mfma_f32_16x16x32_bf16 (4 x 4 tiles of 16 x 16 per wave).  Round 3 had 32x32x16 (2 x 2 of 32 x 32): the
+// same LDS reads and cycles per flop, but under bf16 MFMA load the part holds a higher clock on the 16 x 16 shape
+// (MI355X_MICROARCH.md, DVFS give-back item 7): same-box A/B 9.75 -> 9.49 ms per step, PMC clock of this kernel 2.10-2.16 ->
+// 2.31-2.38 GHz at MFMA busy 0.37-0.43 -> 0.36-0.41.
+template <int BM, int BN, bool PAD>
 __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
 {
     constexpr int WN = BN / 64;
@@ -358,98 +326,48 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
     };
 
     const int nk = p.Kd >> 6;
-    if constexpr (M16) {
-        f32x4 acc[4][4];
+    f32x4 acc[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        // operand fragment of a 16 x 16 x 32 MFMA: lane (row l15, k group kq) holds k = 8 kq .. 8 kq + 7 of the k32 step, i.e. the
-        // 16-byte chunk 4 g + kq of its row; rows 16 i + l15 all carry the swizzle (l15 >> 1) & 7 (conflict-free: the 16 lanes a
-        // ds_read_b128 serves together cover 8 row pairs x 2 chunk parities = 16 distinct slots of the 256-byte bank row)
-        const int l15 = lane & 15, kq = lane >> 4;
-        const int swz = (l15 >> 1) & 7;
-        const int a_rd = (wm * 64 + l15) * 128;
-        const int b_rd = A_BYTES + (wn * 64 + l15) * 128;
-        setup_source(0);
-        stage(0);
-        advance();
-        __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes buffer 0
-        for (int ks = 0; ks < nk; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < nk) { stage(cur ^ 1); advance(); }
-            const unsigned char *sb = smem + cur * STAGE;
-            bf16x8 fa[2][4], fb[2][4];
-            auto read_frags = [&](int g, int q) {
-                const int pos = ((4 * g + kq) ^ swz) * 16;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    fa[q][i] = *(const bf16x8 *)(sb + a_rd + i * (16 * 128) + pos);
-                    fb[q][i] = *(const bf16x8 *)(sb + b_rd + i * (16 * 128) + pos);
-                }
-            };
-            read_frags(0, 0);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int q = g & 1;
-                if (g + 1 < 2) read_frags(g + 1, q ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
-        }
-        igemmb_epilogue<BM, BN>(ep, acc, m0, n0, tid, smem);
-        return;
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int swz = (l31 >> 1) & 7;
-    const int a_rd = (wm * 64 + l31) * 128;
-    const int b_rd = A_BYTES + (wn * 64 + l31) * 128;
-
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    // operand fragment of a 16 x 16 x 32 MFMA: lane (row l15, k group kq) holds k = 8 kq .. 8 kq + 7 of the k32 step, i.e. the
+    // 16-byte chunk 4 g + kq of its row; rows 16 i + l15 all carry the swizzle (l15 >> 1) & 7 (conflict-free: the 16 lanes a
+    // ds_read_b128 serves together cover 8 row pairs x 2 chunk parities = 16 distinct slots of the 256-byte bank row)
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int swz = (l15 >> 1) & 7;
+    const int a_rd = (wm * 64 + l15) * 128;
+    const int b_rd = A_BYTES + (wn * 64 + l15) * 128;
     setup_source(0);
     stage(0);
     advance();
     __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes buffer 0
-
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < nk) { stage(cur ^ 1); advance(); }
         const unsigned char *sb = smem + cur * STAGE;
-        // fragments double-buffered in registers: the reads of k-step g+1 fly while the four MFMAs of g issue (left to itself
-        // the compiler reuses one register set and waits for every group's LDS latency in front of its MFMAs)
-        bf16x8 fa[2][2], fb[2][2];
+        bf16x8 fa[2][4], fb[2][4];
         auto read_frags = [&](int g, int q) {
-            const int pos = ((2 * g + lh) ^ swz) * 16;
-            fa[q][0] = *(const bf16x8 *)(sb + a_rd + pos);
-            fa[q][1] = *(const bf16x8 *)(sb + a_rd + 32 * 128 + pos);
-            fb[q][0] = *(const bf16x8 *)(sb + b_rd + pos);
-            fb[q][1] = *(const bf16x8 *)(sb + b_rd + 32 * 128 + pos);
+            const int pos = ((4 * g + kq) ^ swz) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[q][i] = *(const bf16x8 *)(sb + a_rd + i * (16 * 128) + pos);
+                fb[q][i] = *(const bf16x8 *)(sb + b_rd + i * (16 * 128) + pos);
+            }
         };
         read_frags(0, 0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 2; ++g) {
             const int q = g & 1;
-            if (g + 1 < 4) read_frags(g + 1, q ^ 1);
+            if (g + 1 < 2) read_frags(g + 1, q ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][0], fb[q][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][0], fb[q][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][1], fb[q][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][1], fb[q][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();        // next buffer landed (vmcnt(0)) and this one is free to overwrite
@@ -813,32 +731,25 @@ static int launch_convb64(const IgemmP &p, hipStream_t st)
     return launch_convb64_t<TH, TW, false, false>(p, st);
 }
 
-template <int BM, int BN, bool PAD, bool M16>
-static int launch_cfgb_t(const IgemmP &p, hipStream_t st)
+template <int BM, int BN, bool PAD>
+static int launch_cfgb(const IgemmP &p, hipStream_t st)
 {
     constexpr int STAGES = 2 * (BM + BN) * 128;
     constexpr int EPI = BM * 4 + ((BM + 15) & ~15) + 4 * EPB_WAVE_BYTES;
     constexpr int LDS = STAGES > EPI ? STAGES : EPI;
     static bool attr_done[64] = {false};
-    auto kern = igemmb_kernel<BM, BN, PAD, M16>;
+    auto kern = igemmb_kernel<BM, BN, PAD>;
     if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, attr_done)) return rc_;
     IgemmP q = p;
     q.mtiles = cdiv(p.M, BM);
     q.ntiles = cdiv(p.Nn, BN);
     char tag[96];
-    snprintf(tag, sizeof(tag), "igemmb<%d;%d;%d;%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, M16 ? 16 : 32, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
+    snprintf(tag, sizeof(tag), "igemmb<%d;%d;%d> M=%d N=%d Kd=%d T=%d s=%d nsrc=%d", BM, BN, (int)PAD, p.M, p.Nn, p.Kd, p.T, p.stride, p.nsrc);
     prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * q.mtiles * BM * (double)q.ntiles * BN * p.Kd, igemm_alg_bytes(p) / 2.0);   // every tensor is 2 B/element
     hipLaunchKernelGGL(kern, dim3(q.mtiles * q.ntiles), dim3(256), LDS, st, q);
     prof_end(st);
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-template <int BM, int BN, bool PAD>
-static int launch_cfgb(const IgemmP &p, hipStream_t st)
-{
-    static const int m16 = [] { const char *e = getenv("UNET_IGB_MFMA16"); return e ? atoi(e) : 1; }();
-    return m16 ? launch_cfgb_t<BM, BN, PAD, true>(p, st) : launch_cfgb_t<BM, BN, PAD, false>(p, st);
 }
 
 // p has passed launch_igemm's generic checks; tensors are bf16

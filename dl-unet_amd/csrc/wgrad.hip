@@ -312,14 +312,12 @@ __global__ __launch_bounds__(256, ((TY * TX == 9 && NSPLIT == 0) ? 3 : 2)) void 
 //     two reads per operand fragment, no VALU transposition;
 //   * LDS images are filled by LDS-DMA (8 pixels per instruction); 16-byte chunk c of pixel P sits at chunk c ^ 4((P>>1)&1):
 //     the four pixel rows a half-wave reads then fall on four disjoint bank-row quarters for every tap shift;
-//   * stride-2 taps (up-conv): X pixels are staged de-interleaved by column parity ([tx][pixel]) so that a tap reads
-//     consecutive positions;
 //   * the fused bias gradient is the sum of the fragment values a wave holds anyway (fp32 adds).
 constexpr int PWB = 64;
 template <int TY, int TX, int S>
 struct WgradBGeom {
     static constexpr int T = TY * TX;
-    static constexpr int XPX = S == 1 ? (PWB + TX - 1 + 7) / 8 * 8 : TX * PWB;    // staged X pixel positions per row
+    static constexpr int XPX = (PWB + TX - 1 + 7) / 8 * 8;                         // staged X pixel positions per row
     static constexpr int XG = XPX / 8, YG = PWB / 8;                               // LDS-DMA instructions (8 pixels) per row
     // one row step of prefetch: a second one (5-slot X ring, 3 dz buffers, counted vmcnt) was measured 5 % slower with in-kernel
     // cycle stamps - the wait + barrier share is 3 % of a workgroup's time, what costs is the LDS-DMA issue itself (below)
@@ -328,7 +326,7 @@ struct WgradBGeom {
     static constexpr int LDS = RING * XSLOT + NY * YBUF;
     static constexpr int NI = (S * XG + YG + 3) / 4;                  // LDS-DMA instructions per wave and steady-state row step
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
-    static_assert(S == 1 || (S == 2 && TX == 2), "stride-2 staging assumes 2 taps per row");
+    static_assert(S == 1, "stride-1 layers only: the up-conv weight gradient is wgrad_up_kernel");
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -397,8 +395,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
     int xoff[TX];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-        if (S == 1) xoff[tx] = (8 * f_h + f_q + tx) * 128 + ((cA ^ ((((f_q + tx) >> 1) & 1) << 2)) * 16) + (f_pp & 1) * 8;
-        else xoff[tx] = (tx * PWB + 8 * f_h + f_q) * 128 + ((cA ^ (((f_q >> 1) & 1) << 2)) * 16) + (f_pp & 1) * 8;
+        xoff[tx] = (8 * f_h + f_q + tx) * 128 + ((cA ^ ((((f_q + tx) >> 1) & 1) << 2)) * 16) + (f_pp & 1) * 8;
     }
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)p.X, 0, k.xbytes, 0x00020000);
@@ -424,10 +421,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
 
     auto stage_x = [&](int xr, int slot, int g) {
         const int pos = 8 * g + d_px;
-        int xc; bool ok;
-        if (S == 1) { xc = xcol0 + pos; ok = true; }
-        else { const int tx = pos / PWB, px = pos - tx * PWB; xc = xcol0 + 2 * px + tx; ok = px < pwv; }
-        ok = ok && (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW;
+        const int xc = xcol0 + pos;
+        const bool ok = (unsigned)xr < (unsigned)p.XH && (unsigned)xc < (unsigned)p.XW;
         const int off = (((img * p.XH + xr) * p.XW + xc) * p.XC + p.xc0 + it * 64 + d_c * 8) * 2;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *)(xs + slot * G::XSLOT + g * 1024), 16,
                                                  ok ? off : OOB, 0, 0, 0);
@@ -440,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
     };
     // items of one step: S new X rows (XG groups each) then the Y row; round-robin over waves.  Groups past the strip's
     // last needed pixel are skipped (their LDS content is never read: k-steps stop at nks).
-    const int xg_used = S == 1 ? ((16 * nks + TX - 1 + 7) >> 3) : G::XG;
+    const int xg_used = (16 * nks + TX - 1 + 7) >> 3;
     const int yg_used = 2 * nks;
     // step j (row ya + j) reads the X rows j*S .. j*S + TY-1 of the chunk (ring slot = row index mod RING) and Y buffer j mod NY
     auto stage_step = [&](int y, int j, int first_row, int nrows) {
@@ -472,13 +467,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradK k)
         const int e = wave + 4 * i;
         iv[i] = OOB; il[i] = 0; irr[i] = -1;
         if (e < S * xg_used) {
-            const int rr = (S == 2 && e >= xg_used) ? 1 : 0;
-            const int g = e - rr * xg_used;
+            const int rr = 0;
+            const int g = e;
             const int pos = 8 * g + d_px;
-            int xc; bool ok;
-            if (S == 1) { xc = xcol0 + pos; ok = true; }
-            else { const int tx = pos / PWB, px = pos - tx * PWB; xc = xcol0 + 2 * px + tx; ok = px < pwv; }
-            ok = ok && (unsigned)xc < (unsigned)p.XW;
+            const int xc = xcol0 + pos;
+            const bool ok = (unsigned)xc < (unsigned)p.XW;
             iv[i] = ok ? (xc * p.XC + p.xc0 + it * 64 + d_c * 8) * 2 : OOB;
             il[i] = g * 1024; irr[i] = rr;
         } else if (e < n_items) {
@@ -1050,8 +1043,11 @@ int launch_wgrad(WgradP p, hipStream_t st)
         rc = mode == 2 ? launch_wgrad_up<true>(k, st) : launch_wgrad_up<false>(k, st);
     else if (p.TY == 3 && p.TX == 3 && p.stride == 1)
         rc = mode == 0 ? launch_wgrad_t<3, 3, 1, 0>(k, st) : mode == 1 ? launch_wgrad_t<3, 3, 1, 3>(k, st) : launch_wgrad_b<3, 3, 1>(k, st);
-    else if (p.TY == 2 && p.TX == 2 && p.stride == 2)
-        rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : mode == 1 ? launch_wgrad_t<2, 2, 2, 3>(k, st) : launch_wgrad_b<2, 2, 2>(k, st);
+    else if (p.TY == 2 && p.TX == 2 && p.stride == 2) {
+        // (bf16 tensors: only the pixel-linear kernel - it needs what the bf16 row-walking kernel needed too, tensors below 2 GiB)
+        if (mode == 2) { set_error("wgrad (bf16): the up-conv weight gradient needs tensors below 2 GiB, the full window and buffer-descriptor LDS-DMA"); return -4; }
+        rc = mode == 0 ? launch_wgrad_t<2, 2, 2, 0>(k, st) : launch_wgrad_t<2, 2, 2, 3>(k, st);
+    }
     else { set_error("wgrad: unsupported taps %dx%d stride %d", p.TY, p.TX, p.stride); return -4; }
     if (rc) return rc;
     const int ndb = p.db ? (p.db_on_x ? ci_real : cj_real) : 0;

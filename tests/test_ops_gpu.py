@@ -173,10 +173,19 @@ def test_upconv2_fwd(hip, B, H, Ci, Co):
     assert nerr(nchw(y), ref) < TOL
 
 
+@pytest.fixture(params=[1, 0], ids=["pixel-linear", "row-walking"])
+def up_staging(hip, request):
+    """The up-conv weight gradient runs as the pixel-linear kernel (buffer-descriptor LDS-DMA); with unet_set_lds_dma(0) - what
+    tensors >= 2 GiB take by themselves - it falls back to the row-walking kernel."""
+    hip.check(hip.lib().unet_set_lds_dma(request.param), "set_lds_dma")
+    yield request.param
+    hip.check(hip.lib().unet_set_lds_dma(1), "set_lds_dma")
+
+
 # (the weight gradient is the pixel-linear kernel: fewer pixels than one 32-pixel chunk, a ragged last chunk, chunks that cross
 #  image boundaries, the half-filled channel tiles of the base-32 net, several channel tiles in both directions)
 @pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 18, 128, 64), (1, 5, 64, 64), (3, 11, 64, 32), (5, 6, 256, 256)])
-def test_upconv2_bwd(hip, B, H, Ci, Co):
+def test_upconv2_bwd(hip, B, H, Ci, Co, up_staging):
     keep = Keep()
     x = rnd(B, Ci, H, H, seed=1).clamp_min(0).requires_grad_(True)     # the producer's ReLU output
     w = rnd(Ci, Co, 2, 2, seed=2, scale=0.05).requires_grad_(True)
