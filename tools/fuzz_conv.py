@@ -20,7 +20,9 @@ def run(n, seed, verbose=True):
   rng = random.Random(seed)
   worst = 0.0
   for it in range(n):
-      B = rng.choice([1, 1, 2, 3]); C = rng.choice([64, 64, 128, 192, 256]); K = rng.choice([64, 128, 192, 256])
+      # (32 and 96: the 32-row filter blocks of the Winograd kernel and half-filled weight-gradient tiles; fp32 modes only -
+      #  bf16 tensors need whole 64-channel tiles)
+      B = rng.choice([1, 1, 2, 3]); C = rng.choice([64, 64, 128, 192, 256] + ([] if BF16 else [32, 96])); K = rng.choice([64, 128, 192, 256] + ([] if BF16 else [32, 96]))
       concat = rng.random() < 0.4
       if concat:
           Hs = rng.randint(8, 40); pad = rng.randint(-3, 7); H = Hs + 2 * pad
