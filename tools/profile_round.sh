@@ -5,6 +5,7 @@ set -e
 TAG=$1; shift
 EXTRA="$@"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+rm -rf $OUT            # (gpurun merges a call's files into the local gpurun_out/: delete the local gpurun_out/<tag> before re-using a tag)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16 --detail $OUT/stats_detail.json $EXTRA"
