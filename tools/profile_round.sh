@@ -11,7 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-bf16 --detail $OUT/stats_detail.json $EXTRA"
 # 1. plain bench (the reported line) + per-launch table
 python3 $GRAFT_REPO_ROOT/bench.py --dump-launches $OUT/launches.csv --detail $OUT/bench_detail.json $EXTRA > $OUT/bench.json 2> $OUT/bench.err
-# 2. kernel trace + stats of the same command
+# 2. kernel trace + stats of the same command.  Per-kernel durations and counters are taken on ONE stream: with bf16 tensors the
+#    weight gradients otherwise run next to the dgrad chain (unet_set_overlap default) and every kernel's duration then includes its
+#    neighbour's share of the machine (bench.py's own per-family events switch the overlap off for the steps they sample, too)
+export UNET_OVERLAP=0
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 # 3. PMC passes (own runs, kernel-trace only)
 PB="python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-kernel-timing --detail $OUT/pmc_detail.json $EXTRA"
