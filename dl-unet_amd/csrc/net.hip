@@ -467,8 +467,9 @@ int unet_set_grad_scale(unet_handle *h, float scale)
     return 0;
 }
 
-// -1 (default): per arithmetic mode - on with bf16 tensors (measured +2.6 ... +3 % per step: the weight gradients fill the
-// dgrad chain's partial rounds), off in the fp32 modes (-0.6 ... -1 %: the co-running fp32 MFMA kernels slow each other by more)
+// -1 (default): by what was measured - on with bf16 tensors (+2.6 ... +3 % per step: the weight gradients fill the dgrad chain's
+// partial rounds) and in fp32 at batches of <= 4 tiles (+0.2 ... +1.2 %), off in fp32 at larger batches (-0.6 ... -1 % at B = 8: the
+// co-running fp32 MFMA kernels slow each other by more)
 static int g_overlap = [] { const char *e = getenv("UNET_OVERLAP"); return e ? atoi(e) : -1; }();
 int unet_set_overlap(int on)
 {
@@ -767,7 +768,9 @@ int unet_backward_stage(unet_handle *h, int stage, const void *const *params, co
     ARG_CHECK(stage >= 0 && stage < N_STAGES, "unet_backward: bad stage %d", stage);
     MathScope ms(pl.math);                   // the arithmetic the forward was planned with
     // (no overlap while per-launch events are recorded: launches of two streams would interleave their begin / end events)
-    const bool overlap = (g_overlap < 0 ? pl.math == 2 : g_overlap != 0) && !prof_active();
+    // (fp32 at batches of <= 4 tiles: the deep layers' launches leave CUs idle that the weight gradients can take: +0.7 % at B = 2,
+    //  +1.2 % at B = 1; at B = 8 the two families only get in each other's way)
+    const bool overlap = (g_overlap < 0 ? (pl.math == 2 || pl.B <= 4) : g_overlap != 0) && !prof_active();
     if (overlap && !h->aux) {
         HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

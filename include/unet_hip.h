@@ -104,8 +104,8 @@ int unet_backward(unet_handle *h, const void *const *params, const void *dlogits
                   void *const *grads, void *workspace, size_t workspace_bytes, void *stream);
 /* Weight gradients of each backward stage on an auxiliary stream of the handle, next to the dgrad chain (they only share dz);
  * the streams re-join before unet_backward_stage returns control of `stream`'s order, so callers see no difference (results
- * are bit-identical).  Process-wide: -1 (default; also UNET_OVERLAP) = per arithmetic mode: on with bf16 tensors (+3 % per
- * step), off in the fp32 modes (-1 %); 0 / 1 force it.  Never active while unet_profile_enable(1) records per-launch events
+ * are bit-identical).  Process-wide: -1 (default; also UNET_OVERLAP) = by what was measured: on with bf16 tensors (+3 % per
+ * step) and in fp32 at batches of <= 4 tiles (+0.2 ... +1.2 %), off in fp32 at larger batches (-1 % at B = 8); 0 / 1 force it.  Never active while unet_profile_enable(1) records per-launch events
  * (two streams would interleave them); an event / wait failure fails the stage. */
 int unet_set_overlap(int on);
 int unet_backward_stages(void);
