@@ -573,14 +573,15 @@ def run_rank(args):
             img = torch.floor((0.3 + 0.5 * mask + 0.1 * torch.rand(n, n, generator=g)) * 255)
             return img.to(dev), (mask * 255).to(dev)
         raw = [sample() for _ in range(B)]
+        raw_img, raw_tgt = torch.stack([r[0] for r in raw]), torch.stack([r[1] for r in raw])
         rs = np.random.RandomState(7)
 
         def step():
-            # ImageDataset.__getitem__ after the file reads (data.py:97-135), on the device, per sample like the DataLoader does;
+            # ImageDataset.__getitem__ after the file reads (data.py:97-135) for the batch's samples, on the device;
             # the rotation angle is drawn on the host like the reference's (np.arange(0, 360, 30)); the two uniform fields of the
             # elastic deformation are drawn on the device (host draws + upload: data.augment(random_state=...), 3 ms per field)
-            xs, ys = zip(*[data.augment(im, tg, (0, 0), n, float(rs.choice(np.arange(0, 360, 30))), 200.0, 10.0) for im, tg in raw])
-            images, labels = torch.stack(xs), torch.stack(ys)
+            angles = [float(rs.choice(np.arange(0, 360, 30))) for _ in range(B)]
+            images, labels = data.augment(raw_img, raw_tgt, [(0, 0)] * B, n, angles, 200.0, 10.0)      # the batch's samples in one call
             opt.zero_grad(set_to_none=True)
             preds, loss, labels = trainer._step_loss(net, images, labels, dev, True)      # trainer.py:58-75
             loss.backward()

@@ -133,20 +133,31 @@ def augment(image, target, crop_xy, crop, rot_deg, alpha, sigma, random_state=No
     stay with the caller (crop origin from the weighted distribution + jitter, rot_deg from np.arange(0,360,30), the elastic
     fields), so the host RNG sequence can follow the reference's:  crop -> reflect pad + rotate + centre crop -> the same
     elastic deformation for image and mask -> mask cropped to the label extent and thresholded at 127 -> image to [0,1].
-    image / target: device tensors [H,W] (grey levels / {0,255}); returns (inp [1,S,S] float32, gt [1,crop,crop] int64)."""
-    x0, y0 = crop_xy
-    img = image[x0:x0 + crop, y0:y0 + crop]
-    tgt = target[x0:x0 + crop, y0:y0 + crop]
+    image / target: device tensors [H,W] (grey levels / {0,255}); returns (inp [1,S,S] float32, gt [1,crop,crop] int64).
+    A whole batch in one call (the DataLoader's collate, vectorised): image / target [B,H,W], crop_xy a list of B origins,
+    rot_deg B angles; returns (inp [B,1,S,S], gt [B,1,crop,crop]) - every kernel then runs once for the batch."""
+    batched = image.dim() == 3
+    imgs = image if batched else image[None]
+    tgts = target if batched else target[None]
+    B = imgs.shape[0]
+    origins = list(crop_xy) if batched else [crop_xy]
+    angles = [float(a) for a in (rot_deg if batched else [rot_deg])]
+    if len(origins) != B or len(angles) != B:
+        raise ValueError("need one crop origin and one angle per sample")
+    img = torch.stack([imgs[b, x0:x0 + crop, y0:y0 + crop] for b, (x0, y0) in enumerate(origins)]).float()
+    tgt = torch.stack([tgts[b, x0:x0 + crop, y0:y0 + crop] for b, (x0, y0) in enumerate(origins)]).float()
     _, S, _ = input_size_compute(img)
-    both = reflect_rotate_crop(torch.stack((img.float(), tgt.float())), [rot_deg, rot_deg], S, levels=levels)
-    inp, gt = elastic_transform((both[0], both[1]), alpha, sigma, random_state=random_state, fields=fields)
+    both = reflect_rotate_crop(torch.cat((img, tgt)), angles + angles, S, levels=levels)            # [2B,S,S]: images, then masks
+    inp, gt = elastic_transform((both[:B], both[B:]), alpha, sigma, random_state=random_state, fields=fields)
     if levels:
         # the reference warps the uint8 / uint16 arrays it loaded: scipy's map_coordinates writes its result in the input's
         # type, i.e. rounds t + 0.5 down and clamps to the type's range (data.py:245 on the rotated integer images)
         inp = torch.floor(inp + 0.5).clamp_(0, levels)
         gt = torch.floor(gt + 0.5).clamp_(0, levels)
     pad = int((S - crop) / 2)
-    gt = (gt[pad:crop + pad, pad:crop + pad] > 127).long()
-    lo, hi = inp.min(), inp.max()
+    gt = (gt[:, pad:crop + pad, pad:crop + pad] > 127).long()
+    lo, hi = inp.amin(dim=(1, 2), keepdim=True), inp.amax(dim=(1, 2), keepdim=True)
     inp = (inp - lo) / (hi - lo)
-    return inp[None], gt[None]
+    if batched:
+        return inp[:, None], gt[:, None]
+    return inp[0][None], gt[0][None]

@@ -246,3 +246,24 @@ def test_augment_pipeline_on_device(dev):
     d = np.abs(inp.cpu().numpy()[0] - inp_ref)
     assert d.max() < 2.5 / 255 and (d > 0.6 / 255).mean() < 2e-2, (d.max(), (d > 0.6 / 255).mean())
     assert (gt.cpu().numpy()[0] != gt_ref).mean() < 5e-3
+
+
+def test_augment_batch_equals_per_sample_calls(dev):
+    """data.augment on a batch ([B,H,W] images, one crop origin and one angle per sample) gives exactly what B per-sample calls
+    give with the same elastic fields: the kernels are per-image, only the launches are shared."""
+    import data
+    from oracle import aux_ref
+    n, B = 96, 3
+    ims, tgs = zip(*[aux_ref.cells(10 + b, 160) for b in range(B)])
+    img = torch.from_numpy(np.stack(ims).astype(np.float32)).to(dev)
+    tgt = torch.from_numpy(np.stack(tgs).astype(np.float32)).to(dev)
+    origins = [(5, 9), (40, 0), (64, 64)]
+    angles = [30.0, 0.0, 240.0]
+    S = aux_ref.input_size_compute(n)[1]
+    rs = np.random.RandomState(3)
+    f0 = rs.rand(B, S, S); f1 = rs.rand(B, S, S)
+    xb, gb = data.augment(img, tgt, origins, n, angles, 200.0, 10.0, fields=(f0, f1))
+    assert xb.shape == (B, 1, S, S) and gb.shape == (B, 1, n, n) and gb.dtype == torch.int64
+    for b in range(B):
+        x1, g1 = data.augment(img[b], tgt[b], origins[b], n, angles[b], 200.0, 10.0, fields=(f0[b], f1[b]))
+        assert torch.equal(x1, xb[b]) and torch.equal(g1, gb[b])
