@@ -375,6 +375,230 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
     igemmb_epilogue<BM, BN>(ep, acc, m0, n0, tid, smem);
 }
 
+// ---- band kernel: the 3x3 launches with >= 128 input channels ----------------------------------------------------------------
+// The plain kernel stages the tile's 128 A rows (pixels x 64 channels) once per tap: nine times 16 KiB per channel chunk, of which
+// the three taps of a filter row are the same pixels shifted by one.  Here a filter row's taps share ONE staged band: with the
+// output pixels numbered on the pitch of the input window (q = m + 2 (m / OW): two virtual columns per output row, so that
+// q + 1 is the right-hand neighbour of q for every real pixel), the A row of pixel m at tap (ty, tx) is band row q(m) - q(m0) + tx of
+// the band "tap (ty, 0) of the virtual pixels q(m0) ...".  The M tile stays 128 REAL pixels (nothing is computed for the virtual
+// columns, the epilogue is the plain kernel's); a tile that crosses c output rows needs 130 + 2 c band rows, 144 are staged
+// (launches with OW >= 19).  A band lives for three K steps and is fetched in two halves during the first two of the three steps
+// before them, behind that step's filter tile: the wait at a step's end is a COUNTED vmcnt that retires the filters and leaves the
+// band half in flight across the (raw) barrier - two steps of latency for the band rows, which come from HBM / Infinity Cache,
+// while the filters are L2-hot.  Two band slots + two filter buffers = 68 KiB (two workgroups per CU), LDS-DMA bytes per step
+// 32 -> 22 KiB.  The fragment
+// reads of a lane are the plain kernel's with a per-lane row (its pixel's q) instead of the tile row: the XOR swizzle follows
+// the band row, so every shift reads conflict-free (two lanes collide after the ninth row crossing only).
+struct Igb3P {
+    IgemmP p;
+    FastDiv d_wv, d_oh;      // division by OW + 2 (virtual row pitch) and by OH
+    int Wv, nbands;
+};
+constexpr int IGB3_BAND = 144;                       // staged band rows: 18 LDS-DMA instructions of 8 pixel rows
+
+template <bool PAD>
+__global__ __launch_bounds__(256, 2) void igemmb3_kernel(const Igb3P k)
+{
+    constexpr int BM = 128, BN = 128, WN = 2;
+    constexpr int A_SLOT = IGB3_BAND * 128, B_BYTES = BN * 128, OFF_B = 2 * A_SLOT;
+    constexpr int OOB = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const IgemmP &p = k.p;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const IgEp ep = igb_epilogue_args(p);
+    int a_nsrc = p.nsrc, a_oy0 = p.oy0, a_ox0 = p.ox0, a_Wv = k.Wv, a_nbands = k.nbands;
+    IGB_PIN(a_nsrc); IGB_PIN(a_oy0); IGB_PIN(a_ox0); IGB_PIN(a_Wv); IGB_PIN(a_nbands);
+
+    int logical;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int mt = logical / p.ntiles, nt = logical - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int grow0 = fdiv(m0, ep.d_ow);
+    const int q0 = m0 + 2 * grow0;
+
+    // filter staging: as the plain kernel (thread -> row within a 32-row pass, swizzled source chunk)
+    const int srow = tid >> 3;
+    int b_off[4];
+    {
+        const int coff = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + srow + 32 * j;
+            n = n < p.Nn ? n : p.Nn - 1;
+            b_off[j] = (n * p.ldw + coff) * 2;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, p.buf_bytes[2], 0x00020000);
+
+    // band staging: the 18 instructions of a band (G: band rows 8 G .. 8 G + 7) go out in two halves, during the first and the
+    // second K step of the band before; entry e = 3 h + kk of a thread is G = 9 h + wave + 4 kk (kk = 2: wave 0 only)
+    const int prow = lane >> 3;
+    int a_off[6], a_iy[6], a_ix[6];
+    // the band being fetched ("next"): source, channel chunk, filter row
+    int s = 0, kc = 0, ty = 0, kbase = 0;
+    int sH = 0, sW = 0, sC = 0, snch = 0;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)p.src[0].p, 0, p.buf_bytes[0], 0x00020000);
+    auto setup_source = [&](int si) {
+        const GSrc &g = p.src[si];
+        sH = g.H; sW = g.W; sC = g.C; snch = g.nch;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)g.p, 0, p.buf_bytes[si], 0x00020000);
+        const int nrows = p.NB * ep.OH;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int G = 9 * (e / 3) + wave + 4 * (e % 3);
+            const int r = 8 * G + prow;
+            const int acoff = ((lane & 7) ^ ((r >> 1) & 7)) * 8;          // source chunk of this LDS position (XOR swizzle by band row)
+            const int q = q0 + r;
+            const int grow = fdiv(q, k.d_wv);
+            const int oxv = q - grow * a_Wv;
+            const int img = fdiv(grow, k.d_oh);
+            const int oy = grow - img * ep.OH;
+            const int iy = oy + a_oy0 - g.pad;
+            const int ix = oxv + a_ox0 - g.pad;
+            a_iy[e] = iy; a_ix[e] = ix;
+            a_off[e] = grow < nrows ? (((img * g.H + iy) * g.W + ix) * g.C + g.c0 + acoff) * 2 : OOB;
+            if (PAD && grow >= nrows) a_ix[e] = -1;
+        }
+    };
+    auto stage_a = [&](auto half_tag, int slot) {
+        constexpr int HF = decltype(half_tag)::value;
+        const int so = (ty * sW * sC + kc) * 2;
+        unsigned char *base = smem + slot * A_SLOT + (9 * HF + wave) * 1024;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            if (kk < 2 || wave == 0) {
+                const int e = 3 * HF + kk;
+                int vo = a_off[e] + so;
+                if (PAD) {
+                    const bool inb = (unsigned)(a_iy[e] + ty) < (unsigned)sH && (unsigned)a_ix[e] < (unsigned)sW;
+                    vo = inb ? vo : OOB;
+                }
+                bbuf_lds16(rs_a, base + kk * 4096, vo, 0);
+            }
+        }
+    };
+    auto stage_b = [&](int kglob, int buf) {
+        unsigned char *bbase = smem + OFF_B + buf * B_BYTES + wave * (8 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bbuf_lds16(rs_b, bbase + j * (32 * 128), b_off[j], kglob * 2);
+    };
+    auto advance = [&]() {
+        ++ty;
+        if (ty == 3) {
+            ty = 0;
+            kc += 64;
+            if (kc == snch) {
+                kc = 0;
+                kbase += 9 * snch;
+                ++s;
+                if (s < a_nsrc) setup_source(s);
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: lane (l15, kq) of A tile i reads band row R = q(m) - q0 + tx of its pixel m, chunk (4 g + kq) ^ ((R >> 1) & 7)
+    const int l15 = lane & 15, kq = lane >> 4;
+    int adr_a[4][3][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + wm * 64 + 16 * i + l15;
+        m = m < ep.M ? m : ep.M - 1;
+        const int R0 = (m - m0) + 2 * (fdiv(m, ep.d_ow) - grow0);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            const int R = R0 + tx;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) adr_a[i][tx][g] = R * 128 + (((4 * g + kq) ^ ((R >> 1) & 7)) << 4);
+        }
+    }
+    const int swz = (l15 >> 1) & 7;
+    const int b_rd = OFF_B + (wn * 64 + l15) * 128;
+    const int pos_b0 = (kq ^ swz) * 16, pos_b1 = ((4 + kq) ^ swz) * 16;
+
+    setup_source(0);
+    stage_a(std::integral_constant<int, 0>{}, 0);
+    stage_a(std::integral_constant<int, 1>{}, 0);
+    stage_b(0, 0);
+    int cur_kg0 = 0, cur_snch = snch;
+    advance();
+    __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes band 0 and filter buffer 0
+
+    // one K step: tap (band's filter row, TX) from band slot SLOT and filter buffer BB (all static: immediate LDS offsets)
+    auto step = [&](auto slot_tag, auto tx_tag, int b) {
+        constexpr int SLOT = decltype(slot_tag)::value, TX = decltype(tx_tag)::value;
+        constexpr int BB = (SLOT + TX) & 1;                    // step 3 b + TX, b of SLOT's parity
+        const bool more = b + 1 < a_nbands;
+        // filters of the next step first, then (steps 0 and 1 of a band) one half of the next band: the wait at the end of the step
+        // leaves this step's band half in flight - it is retired by the next step's wait (or by step 2's vmcnt(0))
+        if (TX < 2) stage_b(cur_kg0 + (TX + 1) * cur_snch, BB ^ 1);
+        else if (more) stage_b(kbase + ty * 3 * snch + kc, BB ^ 1);
+        const bool band_dma = TX < 2 && more;
+        if constexpr (TX < 2) { if (band_dma) stage_a(tx_tag, SLOT ^ 1); }
+        const unsigned char *sa = smem + SLOT * A_SLOT;
+        const unsigned char *sb = smem + BB * B_BYTES;
+        bf16x8 fa[2][4], fb[2][4];
+        auto read_frags = [&](auto g_tag, int q) {
+            constexpr int g = decltype(g_tag)::value;
+            const int pos = g ? pos_b1 : pos_b0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[q][i] = *(const bf16x8 *)(sa + adr_a[i][TX][g]);
+                fb[q][i] = *(const bf16x8 *)(sb + b_rd + i * (16 * 128) + pos);
+            }
+        };
+        read_frags(std::integral_constant<int, 0>{}, 0);
+        read_frags(std::integral_constant<int, 1>{}, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g][i], fb[g][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next step's filters have landed (this wave's part; the barrier publishes everybody's) and this step's buffers are free.
+        // A raw barrier: __syncthreads() would drain the band half with vmcnt(0)
+        if (band_dma) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    auto band = [&](auto slot_tag, int b) {
+        step(slot_tag, std::integral_constant<int, 0>{}, b);
+        step(slot_tag, std::integral_constant<int, 1>{}, b);
+        step(slot_tag, std::integral_constant<int, 2>{}, b);
+        if (b + 1 < a_nbands) {
+            cur_kg0 = kbase + ty * 3 * snch + kc; cur_snch = snch;
+            advance();
+        }
+    };
+    for (int b = 0; b < a_nbands; b += 2) {
+        band(std::integral_constant<int, 0>{}, b);
+        if (b + 1 < a_nbands) band(std::integral_constant<int, 1>{}, b + 1);
+    }
+    igemmb_epilogue<BM, BN>(ep, acc, m0, n0, tid, smem);
+}
+
 // =========================================================================================================================
 // convb64: the 64-input-channel 3x3 layers (conv12c, conv21c, conv12e forward; conv12c, conv11e, conv12e dgrad) with bf16
 // tensors.  K = 9 x 64 is nine steps of the kernel above - less time than a workgroup costs around them - and every input
@@ -752,6 +976,42 @@ static int launch_cfgb(const IgemmP &p, hipStream_t st)
     return 0;
 }
 
+static bool igemmb3_applicable(const IgemmP &p)
+{
+    if (!(p.T == 9 && p.TX == 3 && p.stride == 1 && p.Nn % 128 == 0 && p.OW >= 19)) return false;
+    for (int i = 0; i < p.nsrc; ++i)
+        if (p.src[i].nch % 64) return false;
+    // virtual pixel indices (two extra columns per output row) and the band rows past the last tile stay below 2^31
+    return (size_t)p.NB * p.OH * (p.OW + 2) + 1024 < 0x7FFFFFFFull;
+}
+
+template <bool PAD>
+static int launch_igemmb3(const IgemmP &p, hipStream_t st)
+{
+    constexpr int BM = 128, BN = 128;
+    constexpr int STAGES = 2 * IGB3_BAND * 128 + 2 * BN * 128;
+    constexpr int EPI = BM * 4 + ((BM + 15) & ~15) + 4 * EPB_WAVE_BYTES;
+    constexpr int LDS = STAGES > EPI ? STAGES : EPI;
+    static bool attr_done[64] = {false};
+    auto kern = igemmb3_kernel<PAD>;
+    if (int rc_ = ensure_dynamic_lds((const void *)kern, LDS, attr_done)) return rc_;
+    Igb3P k;
+    k.p = p;
+    k.p.mtiles = cdiv(p.M, BM);
+    k.p.ntiles = cdiv(p.Nn, BN);
+    k.Wv = p.OW + 2;
+    k.nbands = p.Kd / 192;
+    k.d_wv = make_fastdiv((unsigned)k.Wv);
+    k.d_oh = make_fastdiv((unsigned)p.OH);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "igemmb3<%d> M=%d N=%d Kd=%d OW=%d nsrc=%d", (int)PAD, p.M, p.Nn, p.Kd, p.OW, p.nsrc);
+    prof_begin(PK_IGEMM, tag, st, igemm_alg_flops(p), 2.0 * k.p.mtiles * BM * (double)k.p.ntiles * BN * p.Kd, igemm_alg_bytes(p) / 2.0);
+    hipLaunchKernelGGL(kern, dim3(k.p.mtiles * k.p.ntiles), dim3(256), LDS, st, k);
+    prof_end(st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // p has passed launch_igemm's generic checks; tensors are bf16
 int launch_igemmb(IgemmP p, bool pad, hipStream_t st)
 {
@@ -776,6 +1036,8 @@ int launch_igemmb(IgemmP p, bool pad, hipStream_t st)
     if (use_cb64 && convb64_applicable(p)) {
         return launch_convb64<8, 32>(p, st);
     }
+    static const int use_band = [] { const char *e = getenv("UNET_IGB_BAND"); return e ? atoi(e) : 1; }();
+    if (use_band && igemmb3_applicable(p)) return pad ? launch_igemmb3<true>(p, st) : launch_igemmb3<false>(p, st);
     if (p.Nn % 128 == 0) return pad ? launch_cfgb<128, 128, true>(p, st) : launch_cfgb<128, 128, false>(p, st);
     return pad ? launch_cfgb<256, 64, true>(p, st) : launch_cfgb<256, 64, false>(p, st);
 }

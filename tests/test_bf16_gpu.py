@@ -62,7 +62,10 @@ def rnd(*shape, seed=0, scale=1.0):
 # (the 64-input-channel shapes take the persistent convb64 kernel: 8 x 32 pixel tiles - extents below / at / just above tile
 #  multiples, one to three 64-channel n-blocks, several tiles per workgroup at 9 x 330 tiles)
 @pytest.mark.parametrize("B,H,C,K", [(2, 21, 64, 64), (1, 37, 64, 128), (3, 14, 128, 128), (1, 12, 256, 512), (2, 45, 64, 64), (1, 66, 512, 512),
-                                     (2, 10, 64, 64), (1, 34, 64, 64), (1, 35, 64, 192), (3, 7, 64, 64), (9, 330, 64, 64)])
+                                     (2, 10, 64, 64), (1, 34, 64, 64), (1, 35, 64, 192), (3, 7, 64, 64), (9, 330, 64, 64),
+                                     # the band kernel (>= 128 input channels, rows of >= 19 outputs): narrowest rows with seven row crossings per
+                                     # tile and an image boundary, an odd number of bands, a ragged last tile over three images, wide rows
+                                     (2, 21, 128, 128), (1, 23, 192, 128), (3, 40, 128, 256), (1, 150, 256, 128), (2, 20, 128, 128)])
 def test_conv3x3_fwd_bf16(hip, B, H, C, K):
     keep = Keep()
     x = bf(rnd(B, C, H, H, seed=1)); w = bf(rnd(K, C, 3, 3, seed=2, scale=0.05)); b = rnd(K, seed=3).float().double()
@@ -74,7 +77,8 @@ def test_conv3x3_fwd_bf16(hip, B, H, C, K):
     assert nerr(nchw(y), ref) < TOL_BF16
 
 
-@pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 24, 4, 64, 64, 64), (2, 30, -3, 64, 64, 128)])
+@pytest.mark.parametrize("B,Hs,pad,C1,C2,K", [(2, 8, 6, 64, 64, 64), (1, 10, 3, 128, 128, 128), (1, 24, 4, 64, 64, 64), (2, 30, -3, 64, 64, 128),
+                                              (2, 20, 4, 128, 128, 128), (1, 40, -5, 128, 64, 256)])
 def test_conv3x3_fwd_virtual_concat_bf16(hip, B, Hs, pad, C1, C2, K):
     keep = Keep()
     H = Hs + 2 * pad
@@ -92,7 +96,10 @@ def test_conv3x3_fwd_virtual_concat_bf16(hip, B, Hs, pad, C1, C2, K):
 # (dgrad of a K = 64 layer is a 64-input-channel launch with two pixels of virtual zero padding: convb64 with border tiles)
 @pytest.mark.parametrize("B,H,C,K,use_mask,use_add", [(2, 21, 64, 64, True, False), (1, 38, 64, 128, False, True), (2, 13, 128, 256, True, True),
                                                       (1, 70, 64, 64, True, False), (1, 66, 512, 512, True, True), (1, 150, 64, 64, False, False),
-                                                      (2, 34, 64, 64, True, True), (1, 9, 128, 64, True, False), (5, 200, 64, 64, True, False)])
+                                                      (2, 34, 64, 64, True, True), (1, 9, 128, 64, True, False), (5, 200, 64, 64, True, False),
+                                                      # dgrad through the band kernel (two pixels of virtual padding on every side)
+                                                      (2, 23, 128, 128, True, True), (1, 30, 256, 192, False, False), (3, 27, 128, 128, True, False),
+                                                      (2, 19, 128, 128, False, True)])
 def test_conv3x3_bwd_bf16(hip, B, H, C, K, use_mask, use_add):
     keep = Keep()
     x = bf(rnd(B, C, H, H, seed=1)).requires_grad_(True)
@@ -118,7 +125,8 @@ def test_conv3x3_bwd_bf16(hip, B, H, C, K, use_mask, use_add):
     assert nerr(db, dz.sum((0, 2, 3))) < TOL_F32
 
 
-@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 24, 4, 64, 64), (2, 30, -3, 64, 128)])
+@pytest.mark.parametrize("B,Hs,pad,C,K", [(2, 8, 6, 64, 64), (1, 12, 3, 128, 128), (1, 24, 4, 64, 64), (2, 30, -3, 64, 128),
+                                          (1, 20, 4, 128, 128), (2, 34, -4, 128, 128)])
 def test_conv3x3_bwd_virtual_concat_bf16(hip, B, Hs, pad, C, K):
     keep = Keep()
     H = Hs + 2 * pad
