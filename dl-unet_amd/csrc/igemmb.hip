@@ -387,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void igemmb_kernel(const IgemmP p)
 // band half in flight across the (raw) barrier - two steps of latency for the band rows, which come from HBM / Infinity Cache,
 // while the filters are L2-hot.  Two band slots + two filter buffers = 68 KiB (two workgroups per CU), LDS-DMA bytes per step
 // 32 -> 22 KiB.  The fragment
-// reads of a lane are the plain kernel's with a per-lane row (its pixel's q) instead of the tile row: the XOR swizzle follows
-// the band row, so every shift reads conflict-free (two lanes collide after the ninth row crossing only).
+// reads of a lane are the plain kernel's with a per-lane row (its pixel's q) instead of the tile row: the swizzle follows
+// the band row and is conflict-free for every shift (a row crossing inside a 16-row group costs a two-way conflict).
 struct Igb3P {
     IgemmP p;
     FastDiv d_wv, d_oh;      // division by OW + 2 (virtual row pitch) and by OH
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void igemmb3_kernel(const Igb3P k)
         for (int e = 0; e < 6; ++e) {
             const int G = 9 * (e / 3) + wave + 4 * (e % 3);
             const int r = 8 * G + prow;
-            const int acoff = ((lane & 7) ^ ((r >> 1) & 7)) * 8;          // source chunk of this LDS position (XOR swizzle by band row)
+            const int acoff = ((lane & 7) ^ (((r >> 1) & 3) << 1)) * 8;   // source chunk of this LDS position (swizzle by band row, below)
             const int q = q0 + r;
             const int grow = fdiv(q, k.d_wv);
             const int oxv = q - grow * a_Wv;
@@ -511,7 +511,12 @@ __global__ __launch_bounds__(256, 2) void igemmb3_kernel(const Igb3P k)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    // fragment reads: lane (l15, kq) of A tile i reads band row R = q(m) - q0 + tx of its pixel m, chunk (4 g + kq) ^ ((R >> 1) & 7)
+    // fragment reads: lane (l15, kq) of A tile i reads band row R = q(m) - q0 + tx of its pixel m, chunk (4 g + kq) ^ 2 ((R >> 1) & 3).
+    // The swizzle must be conflict-free for every shift tx: a ds_read_b128 serves 16 lanes together - 16 consecutive rows, the k
+    // groups kq and kq ^ 1 in a fixed pattern (row pairs 0, 1, 6, 7 of the sixteen one group, 2 ... 5 the other).  The plain
+    // kernel's (R >> 1) & 7 relies on that pattern staying aligned with the row pairs; shifted by one row it collides two ways
+    // (PMC: LDS conflict cycles 0.26 of all).  XORing bits 1-2 only leaves bit 0 = kq: two lanes of one row parity then differ
+    // in the row pair mod 4 or, four pairs apart, in kq - whatever the shift.
     const int l15 = lane & 15, kq = lane >> 4;
     int adr_a[4][3][2];
 #pragma unroll
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void igemmb3_kernel(const Igb3P k)
         for (int tx = 0; tx < 3; ++tx) {
             const int R = R0 + tx;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) adr_a[i][tx][g] = R * 128 + (((4 * g + kq) ^ ((R >> 1) & 7)) << 4);
+            for (int g = 0; g < 2; ++g) adr_a[i][tx][g] = R * 128 + (((4 * g + kq) ^ (((R >> 1) & 3) << 1)) << 4);
         }
     }
     const int swz = (l15 >> 1) & 7;
