@@ -761,7 +761,7 @@ def run_rank(args):
                            "tensors the weight gradients run on the handle's auxiliary stream next to the dgrad chain (unet_set_overlap default); "
                            "`frac` comes from the region's last two steps, which carry per-launch events and therefore run on one stream"}
             if st_b is not None and st_b[0] > 0:
-                blk.update({"kernel": "igemmb+convb64", "frac": st_b[3] / (st_b[0] * 1e-3) / 1e12 / PEAK_TFLOPS[2], "peak": PEAK_TFLOPS[2],
+                blk.update({"kernel": "igemmb3+igemmb+convb64", "frac": st_b[3] / (st_b[0] * 1e-3) / 1e12 / PEAK_TFLOPS[2], "peak": PEAK_TFLOPS[2],
                             "avg_launch_ms": st_b[0] / max(st_b[1], 1), "launches_per_step": st_b[1] / ns_b,
                             "share_of_step_time": (st_b[0] / ns_b) / (dtb / nb * 1e3)})
             out["bf16"] = blk

@@ -171,7 +171,7 @@ def test_bench_line_is_short_and_keeps_the_contract_fields():
     full["comm"] = {"gradient_allreduce": "rccl", "ranks": 8, "rccl_version": 22204, "message_mb": 124.1, "buckets": 6,
                     "self_launched": True, "allreduce_ms_per_step": 1.234567, "exposed_ms_per_step": 0.123456}
     full["roofline"]["traffic_source"] = bench.pmc_traffic(3, "wino", 8)[1] + " " * 0
-    full["bf16"] = {"ms_per_step": 9.56123456, "tiles_per_s": 836.7123456, "steps": 10, "warmup": 3, "kernel": "igemmb+convb64", "frac": 0.3612345,
+    full["bf16"] = {"ms_per_step": 9.56123456, "tiles_per_s": 836.7123456, "steps": 10, "warmup": 3, "kernel": "igemmb3+igemmb+convb64", "frac": 0.3612345,
                     "peak": 2500.0, "logits_err": 0.0181234, "argmax_flips": 39, "px": 150544, "what": "x" * 400, "parity_note": "y" * 300}
     line, detail = bench.split_line(full, "gpurun_out/bench_detail.json")
     assert len(json.dumps(line["bf16"])) <= 300 and "what" not in line["bf16"]
