@@ -146,6 +146,62 @@ def test_conv3x3_bwd_virtual_concat_bf16(hip, B, Hs, pad, C, K):
     assert nerr(db, dz.sum((0, 2, 3))) < TOL_F32
 
 
+_BAND_AB = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "dl-unet_amd"))
+import torch
+import _hip
+L = _hip.lib()
+_hip.check(L.unet_set_math(2), "set_math")
+torch.cuda.set_device(0)
+g = torch.Generator().manual_seed(7)
+def rnd(*s, scale=1.0):
+    return (torch.randn(*s, generator=g) * scale)
+h = hashlib.sha256()
+keep = []
+def dev16(t):
+    t = t.to(torch.bfloat16).cuda(); keep.append(t); return t
+def dev32(t):
+    t = t.float().cuda(); keep.append(t); return t
+# (B, H, C1, C2, pad of source 1, K): single source, two sources with positive / negative pad (crop), ragged tiles, narrowest rows
+for B, H, C1, C2, pad, K in [(2, 21, 128, 0, 0, 128), (3, 40, 256, 0, 0, 256), (1, 150, 128, 0, 0, 128), (2, 28, 128, 128, 4, 128),
+                             (1, 30, 128, 64, -5, 256), (8, 30, 1024, 0, 0, 1024)]:
+    Hs = H - 2 * pad
+    C = C1 + C2
+    a = dev16(rnd(B, Hs if C2 else H, Hs if C2 else H, C1)); u = dev16(rnd(B, H, H, C2)) if C2 else None
+    w = dev32(rnd(K, C, 3, 3, scale=0.05).to(torch.bfloat16)); b = dev32(rnd(K))
+    y = torch.empty(B, H - 2, H - 2, K, device="cuda", dtype=torch.bfloat16)
+    sc = torch.empty(max(int(L.unet_conv3x3_scratch_bytes(C, K)), 256), dtype=torch.uint8, device="cuda")
+    _hip.check(L.unet_conv3x3_fwd(_hip.ptr(a), Hs if C2 else H, Hs if C2 else H, C1, pad, _hip.ptr(u) if C2 else None, C2, B, H, H, _hip.ptr(w), _hip.ptr(b), K, 1,
+                                  _hip.ptr(y), _hip.ptr(sc), _hip.stream()), "fwd")
+    h.update(y.view(torch.int16).cpu().numpy().tobytes())
+    if not C2:
+        dz = dev16(rnd(B, H - 2, H - 2, K)); mask = dev16(rnd(B, H, H, C).clamp_min(0)); add = dev16(rnd(B, H, H, C))
+        dx = torch.empty(B, H, H, C, device="cuda", dtype=torch.bfloat16)
+        dw = torch.empty(K, C, 3, 3, device="cuda"); db = torch.empty(K, device="cuda")
+        sc2 = torch.empty(max(int(L.unet_conv3x3_bwd_scratch_bytes(B, H, H, C, K)), 256), dtype=torch.uint8, device="cuda")
+        _hip.check(L.unet_conv3x3_bwd(_hip.ptr(a), H, H, C, 0, None, 0, B, H, H, _hip.ptr(w), K, _hip.ptr(dz), _hip.ptr(dx), _hip.ptr(mask), _hip.ptr(add),
+                                      None, None, _hip.ptr(dw), _hip.ptr(db), _hip.ptr(sc2), _hip.stream()), "bwd")
+        h.update(dx.view(torch.int16).cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_band_kernel_is_bit_identical_to_the_plain_implicit_gemm(hip):
+    """The band-staged kernel (igemmb3) and the plain one (UNET_IGB_BAND=0) contract in the same K order with the same MFMA:
+    forward and dgrad outputs must agree BIT FOR BIT - any wrong band row, tap shift, padding or concat offset would show.
+    Two child processes (the switch is read once per process), one GPU process at a time."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for band in ("1", "0"):
+        env = dict(os.environ, UNET_IGB_BAND=band)
+        out = subprocess.run([sys.executable, "-c", _BAND_AB, root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
+
+
 @pytest.mark.parametrize("B,H,Ci,Co", [(2, 7, 128, 64), (1, 13, 256, 128), (1, 4, 1024, 512), (1, 40, 128, 64), (1, 5, 64, 64), (5, 6, 256, 256)])
 def test_upconv2_fwd_bwd_bf16(hip, B, H, Ci, Co):
     keep = Keep()
